@@ -1,0 +1,198 @@
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference; CPU).  Usage:
+    python tests/golden/make_golden.py [path2] [vidtome] [pipeline]
+
+The reference modules are imported in place (nothing is copied): `utils.VidToMe` is registered
+as an empty namespace so its __init__ (diffusers/torchvision/cv2) is bypassed; absent
+third-party modules that the hot functions never call are stubbed; the two pytorch_msssim
+helpers loss_utils.py:19-20 imports are restated (third-party, unpinned -> that leaf is
+"parity unpinned").  Inputs are regenerated from seeds by tests/synth.py, so the fixtures hold
+only expected outputs.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    pkg = types.ModuleType("utils.VidToMe")
+    pkg.__path__ = [REF + "/utils/VidToMe"]
+    sys.modules["utils.VidToMe"] = pkg
+    mods = {"vidtome": importlib.import_module("utils.VidToMe.vidtome")}
+    sys.modules["torch_scatter"] = types.ModuleType("torch_scatter")
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tv.transforms, "torchvision.models": tv.models})
+    pm, pms = types.ModuleType("pytorch_msssim"), types.ModuleType("pytorch_msssim.ssim")
+    pm.ms_ssim = None
+
+    def _fspecial_gauss_1d(size, sigma):
+        c = torch.arange(size, dtype=torch.float) - size // 2
+        g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+        return (g / g.sum())[None, None]
+
+    def gaussian_filter(x, win):
+        c = x.shape[1]
+        out = x
+        for i, s in enumerate(x.shape[2:]):
+            if s >= win.shape[-1]:
+                out = F.conv2d(out, win.transpose(2 + i, -1), stride=1, padding=0, groups=c)
+        return out
+
+    pms._fspecial_gauss_1d, pms.gaussian_filter = _fspecial_gauss_1d, gaussian_filter
+    sys.modules.update({"pytorch_msssim": pm, "pytorch_msssim.ssim": pms})
+    for m in ("flow_utils", "loss_utils", "general_utils", "sh_utils", "dataloader"):
+        mods[m] = importlib.import_module("utils." + m)
+    return mods
+
+
+def sub(t, k=97):
+    """Strided subsample of a flattened tensor (keeps fixtures small)."""
+    return t.detach().reshape(-1)[::k].numpy().copy()
+
+
+def golden_path2(R):
+    fu, lu, gu, sh, dl = R["flow_utils"], R["loss_utils"], R["general_utils"], R["sh_utils"], R["dataloader"]
+    out = {}
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 200, 208)
+    y = (x + 0.05 * torch.randn_like(x)).clamp(0, 1)
+    out["ka_msssim"] = float(lu.relaxed_ms_ssim(x, y, data_range=1, start_level=1))
+    out["ka_tv"] = float(lu.TVLoss(0.05)(x))
+    out["ka_l1"] = float(lu.l1_loss(x, y))
+    out["ka_lr50"] = float(gu.get_expon_lr_func(0.01, 0.001, 0, 0.0, max_steps=100)(50))
+    out["lr_curve"] = np.array([gu.get_expon_lr_func(0.01, 0.001, 0, 0.0, max_steps=70)(s) for s in range(0, 75, 5)])
+
+    d = synth.video_clip(4, 176, 192, seed=11)
+    ed, fl, mk = d["edited"], d["past_flows"], d["masks"]
+    # warp_flow forward + grad wrt frames
+    fr = ed.clone().requires_grad_(True)
+    wv = fu.warp_flow(fr, fl * 3.0)
+    gsel = torch.from_numpy(np.random.default_rng(5).standard_normal(wv.shape).astype(np.float32))
+    (wv * gsel).sum().backward()
+    out["warp_fwd"], out["warp_grad"] = sub(wv), sub(fr.grad)
+    # ms-ssim forward + grad, odd sizes exercise the padding=size%2 pooling
+    for tag, (hh, ww) in {"a": (176, 192), "b": (181, 203)}.items():
+        xa = ed[:2, :, :hh, :ww] if hh <= 176 else F.interpolate(ed[:2], size=(hh, ww), mode="bilinear")
+        xa = xa.clone().requires_grad_(True)
+        ya = (xa.detach() * 0.9 + 0.05).clamp(0, 1) + 0.02 * torch.from_numpy(
+            np.random.default_rng(6).standard_normal(xa.shape).astype(np.float32))
+        v = lu.relaxed_ms_ssim(xa, ya, data_range=1, start_level=1)
+        v.backward()
+        out[f"msssim_{tag}"], out[f"msssim_{tag}_grad"] = float(v), sub(xa.grad)
+    xt = ed[:2].clone().requires_grad_(True)
+    tvv = lu.TVLoss(0.05)(xt)
+    tvv.backward()
+    out["tv"], out["tv_grad"] = float(tvv), sub(xt.grad)
+    # AdaIN (general_utils.py:137-156)
+    g = np.random.default_rng(8)
+    c = torch.from_numpy(g.standard_normal((5, 4, 24, 32)).astype(np.float32)) * 1.7 + 0.3
+    s = torch.from_numpy(g.standard_normal((5, 4, 24, 32)).astype(np.float32)) * 0.6 - 0.2
+    out["adain"] = gu.adaptive_instance_normalization(c, s).numpy()
+    # soft masks / flow ids / voxelization on a small clip
+    d5 = synth.video_clip(5, 48, 64, seed=21, shift=(1.0, 0.0), jitter=0.0)
+    fwd = -d5["past_flows"].roll(-1, 0)
+    fwd[-1] = 0
+    sm = fu.get_soft_mask_bwds(d5["frames"], fwd, d5["past_flows"], alpha=0.5)
+    out["softmask"] = sm.numpy()
+    ids = fu.get_flowid(d5["frames"], fwd, sm, rgb_threshold=0.01)
+    out["flowid"] = ids.numpy().astype(np.int64)
+    inv = gu.voxelization(ids.reshape(-1, 1), d5["frames"].permute(0, 2, 3, 1).reshape(-1, 3), None, None)
+    out["unq_inv_equal_ids"] = bool((inv == ids.reshape(-1).long()).all())
+
+    # ---- stage 1: 3 iterations transcribed with the reference's leaves + torch.optim.Adam + OptDataset
+    n, _, h, w = ed.shape
+    bs = 2
+    bts = synth.batches(n, bs, epochs=2, seed=7)[:3]
+    ds = dl.OptDataset(ed.clone(), fl, mk, device="cpu")
+    expo = torch.nn.Parameter(torch.eye(3, 4)[None].repeat(n, 1, 1))
+    opt = torch.optim.Adam([expo])
+    lr_fn = gu.get_expon_lr_func(0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0, max_steps=2 * n // bs)
+    losses = []
+    for it, idx in enumerate(bts):
+        epoch, i = divmod(it, n // bs)
+        for pg in opt.param_groups:
+            pg["lr"] = lr_fn(epoch * n // bs + i + 1)
+        items = [ds[int(j)] for j in idx]
+        edited = torch.stack([t[1] for t in items])
+        pre = torch.stack([t[2] for t in items])
+        pf = torch.stack([t[3] for t in items])
+        mb = torch.stack([t[4] for t in items])
+        cat = torch.cat([edited, pre])
+        cidx = torch.cat([idx, idx - 1])
+        cidx[cidx < 0] = 0
+        flat = cat.permute(0, 2, 3, 1).reshape(-1, h * w, 3)
+        tr = torch.bmm(flat, expo[cidx, :3, :3]) + expo[cidx, None, :3, 3]
+        cat = tr.clamp(0, 1).reshape(-1, h, w, 3).permute(0, 3, 1, 2)
+        img, pimg = cat[:len(idx)], cat[len(idx):]
+        lp = lu.l1_loss(img, edited) * 0.8 + (1.0 - lu.relaxed_ms_ssim(img, edited, data_range=1, start_level=1)) * 0.2
+        wp = fu.warp_flow(pimg, pf)
+        valid = idx > 0
+        lf = lu.l1_loss(wp[valid] * mb[valid], img[valid] * mb[valid])
+        loss = 0.2 * lp + 0.8 * lf
+        losses.append(float(loss))
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    ds.exposure_align(expo.detach())
+    out["s1_losses"], out["s1_exposure"], out["s1_images"] = np.array(losses), expo.detach().numpy(), sub(ds.edited_images)
+
+    # ---- stage 2: 3 iterations (generate.py:472-533) on track ids
+    inv, K = synth.track_ids(n, h, w, seed=3)
+    pix = ed.permute(0, 2, 3, 1).reshape(n * h * w, 3)
+    sm_sum = torch.zeros(K, 3).index_add_(0, inv, pix)
+    cnt = torch.bincount(inv, minlength=K).clamp(min=1)[:, None]
+    feats = torch.nn.Parameter(sh.RGB2SH(sm_sum / cnt).contiguous())   # torch_scatter mean restated (unpinned leaf)
+    opt = torch.optim.Adam([{"params": [feats], "lr": 0.05 * bs / n}], lr=0.0, eps=1e-15)
+    tvl = lu.TVLoss(0.05)
+    ds2 = dl.OptDataset(ed.clone(), fl, mk, device="cpu")
+    losses = []
+    for idx in bts:
+        items = [ds2[int(j)] for j in idx]
+        edited = torch.stack([t[1] for t in items])
+        pf = torch.stack([t[3] for t in items])
+        mb = torch.stack([t[4] for t in items])
+        cidx = torch.cat([idx, idx - 1])
+        cidx[cidx < 0] = 0
+        ui = inv.reshape(n, h, w, -1)[cidx].reshape(-1)
+        cat = torch.index_select(sh.SH2RGB(feats), 0, ui).clamp(0, 1).reshape(len(cidx), h, w, 3).permute(0, 3, 1, 2)
+        img, pimg = cat[:len(idx)], cat[len(idx):]
+        wp = fu.warp_flow(pimg, pf)
+        valid = idx > 0
+        lf = lu.l1_loss(wp[valid] * mb[valid], img[valid] * mb[valid])
+        lp = (1.0 - lu.relaxed_ms_ssim(img, edited, data_range=1, start_level=1)) * 0.2
+        loss = 0.2 * lp + 0.8 * lf + tvl(img)
+        losses.append(float(loss))
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    out["s2_losses"], out["s2_feats"] = np.array(losses), sub(feats, 31)
+    np.savez_compressed(os.path.join(HERE, "path2.npz"), **out)
+    print("path2.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
+GROUPS = {"path2": golden_path2}
+
+if __name__ == "__main__":
+    R = import_reference()
+    try:
+        from make_golden_path1 import GROUPS as G1
+        GROUPS.update(G1)
+    except ImportError:
+        pass
+    for g in (sys.argv[1:] or list(GROUPS)):
+        GROUPS[g](R)

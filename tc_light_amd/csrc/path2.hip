@@ -1,0 +1,622 @@
+// Path 2 of TC-Light on gfx950: the two-stage temporal-consistency optimiser.
+// HBM-bound f32 kernels, forward and hand-derived backward fused per loss term, plus the
+// whole-stage drivers that enqueue every iteration on one HIP stream with no host sync
+// (the reference synchronises on loss.item() every iteration, generate.py:431,513).
+//
+// Layout: images planar [n,3,H,W] f32 (the reference's NCHW), flows [N,2,H,W], masks [N,1,H,W],
+// unq_inv int32 [N*H*W], codebook [K,3], exposure [N,3,4].
+// Reference functions restated (file:line under /root/reference):
+//   warp_flow utils/flow_utils.py:5-16 · relaxed_ms_ssim utils/loss_utils.py:73-211 · TVLoss :324-340
+//   l1_loss :25-26 · exposure_align generate.py:354-451 · unique_tensor_optimization :453-533
+//   OptDataset.exposure_align utils/dataloader.py:38-42 · SH2RGB/RGB2SH utils/sh_utils.py:114-117
+#include "common.h"
+#include "../../include/tclight_hip.h"
+#include <math.h>
+#include <string.h>
+
+#define SH_C0 0.28209479177387814f
+#define TW 32
+#define TH 16
+#define HALO 10
+#define TIW (TW + HALO)
+#define TIH (TH + HALO)
+
+struct Gauss11 { float g[11]; };
+static Gauss11 make_gauss() {
+    Gauss11 G; float s = 0.f;
+    for (int i = 0; i < 11; ++i) { float c = (float)(i - 5); G.g[i] = expf(-(c * c) / (2.f * 1.5f * 1.5f)); s += G.g[i]; }
+    for (int i = 0; i < 11; ++i) G.g[i] /= s;
+    return G;
+}
+
+// ---------------------------------------------------------------- bicubic (A=-0.75, zeros, align_corners)
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    float x = t + 1.f;
+    w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    x = 1.f - t;
+    w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 2.f - t;
+    w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+struct Tap { int x0, y0; float wx[4], wy[4]; };
+__device__ __forceinline__ Tap make_tap(float fx, float fy, int x, int y, int W, int H) {
+    // same float sequence as the reference: normalise to [-1,1] (flow_utils.py:12-13) then un-normalise
+    float gx = ((fx + (float)x) / (float)(W - 1) - 0.5f) * 2.f;
+    float gy = ((fy + (float)y) / (float)(H - 1) - 0.5f) * 2.f;
+    float ix = (gx + 1.f) * 0.5f * (float)(W - 1);
+    float iy = (gy + 1.f) * 0.5f * (float)(H - 1);
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    Tap t; t.x0 = (int)fx0 - 1; t.y0 = (int)fy0 - 1;
+    cubic_w(ix - fx0, t.wx); cubic_w(iy - fy0, t.wy);
+    return t;
+}
+
+__global__ void k_warp_fwd(const float* __restrict__ img, const float* __restrict__ flow, float* __restrict__ out,
+                           int C, int H, int W, int flow_c) {
+    const int P = H * W, n = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int y = p / W, x = p - y * W;
+        const float* fl = flow + (size_t)n * flow_c * P;
+        Tap t = make_tap(fl[p], fl[P + p], x, y, W, H);
+        for (int c = 0; c < C; ++c) {
+            const float* pl = img + ((size_t)n * C + c) * P;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int yy = t.y0 + j; if (yy < 0 || yy >= H) continue;
+                float r = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { int xx = t.x0 + i; if (xx >= 0 && xx < W) r += t.wx[i] * pl[yy * W + xx]; }
+                acc += t.wy[j] * r;
+            }
+            out[((size_t)n * C + c) * P + p] = acc;
+        }
+    }
+}
+__global__ void k_warp_bwd(const float* __restrict__ gout, const float* __restrict__ flow, float* __restrict__ gimg,
+                           int C, int H, int W, int flow_c) {
+    const int P = H * W, n = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int y = p / W, x = p - y * W;
+        const float* fl = flow + (size_t)n * flow_c * P;
+        Tap t = make_tap(fl[p], fl[P + p], x, y, W, H);
+        for (int c = 0; c < C; ++c) {
+            float g = gout[((size_t)n * C + c) * P + p];
+            float* pl = gimg + ((size_t)n * C + c) * P;
+            for (int j = 0; j < 4; ++j) {
+                int yy = t.y0 + j; if (yy < 0 || yy >= H) continue;
+                for (int i = 0; i < 4; ++i) { int xx = t.x0 + i; if (xx >= 0 && xx < W) atomicAdd(pl + yy * W + xx, t.wy[j] * t.wx[i] * g); }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- parameter -> image
+// out[j] = clamp(src[idx[j]] @ M[:3,:3] + M[:3,3]) (generate.py:405-407)
+__global__ void k_apply_exposure(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ expo,
+                                 float* __restrict__ out, int P) {
+    const int j = blockIdx.y, f = idx ? idx[j] : j;
+    const float* M = expo + (size_t)f * 12;
+    float m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = M[i];
+    const float* s = src + (size_t)f * 3 * P; float* o = out + (size_t)j * 3 * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        float x0 = s[p], x1 = s[P + p], x2 = s[2 * P + p];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = x0 * m[c] + x1 * m[4 + c] + x2 * m[8 + c] + m[c * 4 + 3];
+            o[c * P + p] = fminf(fmaxf(t, 0.f), 1.f);
+        }
+    }
+}
+// grad_expo[f] += d(loss)/dM from grad of the clamped output (atomics: one set of 12 per block)
+__global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ expo,
+                               const float* __restrict__ gout, float* __restrict__ gexpo, int P) {
+    __shared__ float red[16];
+    const int j = blockIdx.y, f = idx[j];
+    const float* M = expo + (size_t)f * 12;
+    float m[12], acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { m[i] = M[i]; acc[i] = 0.f; }
+    const float* s = src + (size_t)f * 3 * P; const float* g = gout + (size_t)j * 3 * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        float x[3] = {s[p], s[P + p], s[2 * P + p]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = x[0] * m[c] + x[1] * m[4 + c] + x[2] * m[8 + c] + m[c * 4 + 3];
+            float gc = (t >= 0.f && t <= 1.f) ? g[c * P + p] : 0.f;
+            acc[c] += x[0] * gc; acc[4 + c] += x[1] * gc; acc[8 + c] += x[2] * gc; acc[c * 4 + 3] += gc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float r = block_sum(acc[i], red);
+        if (threadIdx.x == 0 && r != 0.f) atomicAdd(gexpo + (size_t)f * 12 + i, r);
+    }
+}
+// out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
+__global__ void k_gather_codebook(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
+                                  float* __restrict__ out, int P) {
+    const int j = blockIdx.y, f = fidx ? fidx[j] : j;
+    const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float* r = feat + (size_t)iv[p] * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c * P + p] = fminf(fmaxf(r[c] * SH_C0 + 0.5f, 0.f), 1.f);
+    }
+}
+__global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
+                               const float* __restrict__ gout, float* __restrict__ gfeat, int P) {
+    const int j = blockIdx.y, f = fidx[j];
+    const int* iv = inv + (size_t)f * P; const float* g = gout + (size_t)j * 3 * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        size_t id = (size_t)iv[p] * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = feat[id + c] * SH_C0 + 0.5f, gc = g[c * P + p];
+            if (v >= 0.f && v <= 1.f && gc != 0.f) atomicAdd(gfeat + id + c, gc * SH_C0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- MS-SSIM
+// avg_pool2d(k=2, padding=size%2, count_include_pad) of nplanes planes; if fidx != null the source
+// plane of output plane q is (fidx[q/3]*3 + q%3) (used to pool the target frames in place).
+__global__ void k_pool2(const float* __restrict__ in, const int* __restrict__ fidx, float* __restrict__ out,
+                        int h, int w, int oh, int ow) {
+    const int q = blockIdx.y, ph = h & 1, pw = w & 1;
+    const float* s = in + (size_t)(fidx ? fidx[q / 3] * 3 + q % 3 : q) * h * w;
+    float* o = out + (size_t)q * oh * ow;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < oh * ow; i += gridDim.x * blockDim.x) {
+        int oy = i / ow, ox = i - oy * ow, y0 = 2 * oy - ph, x0 = 2 * ox - pw;
+        float a = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int y = y0 + dy, x = x0 + dx;
+                if (y >= 0 && y < h && x >= 0 && x < w) a += s[y * w + x];
+            }
+        o[i] = a * 0.25f;
+    }
+}
+// One SSIM level: 'valid' separable 11-tap Gaussian of X, Y, XX, YY, XY through LDS, cs (and
+// luminance on the last level) map -> per-plane sum, and the three local-derivative maps
+// (d/d sigma12, d/d sigma1^2, d/d mu1-equivalent) the backward pass filters back.
+__global__ __launch_bounds__(256) void k_ssim_fwd(const float* __restrict__ X, const float* __restrict__ Y, int h, int w, int last,
+                                                  float c1, float c2, Gauss11 G, float* __restrict__ mA, float* __restrict__ mB,
+                                                  float* __restrict__ mC, float* __restrict__ sums) {
+    __shared__ float sx[TIH][TIW + 1], sy[TIH][TIW + 1];
+    __shared__ float hz[5][TIH][TW];
+    __shared__ float red[16];
+    const int q = blockIdx.z, oh = h - HALO, ow = w - HALO, tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const float* xp = X + (size_t)q * h * w; const float* yp = Y + (size_t)q * h * w;
+    for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
+        int r = i / TIW, c = i - r * TIW, gy = ty0 + r, gx = tx0 + c;
+        bool in = gy < h && gx < w;
+        sx[r][c] = in ? xp[gy * w + gx] : 0.f;
+        sy[r][c] = in ? yp[gy * w + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TIH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float x = sx[r][c + k], y = sy[r][c + k], g = G.g[k];
+            a0 += g * x; a1 += g * y; a2 += g * x * x; a3 += g * y * y; a4 += g * x * y;
+        }
+        hz[0][r][c] = a0; hz[1][r][c] = a1; hz[2][r][c] = a2; hz[3][r][c] = a3; hz[4][r][c] = a4;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int o = threadIdx.x; o < TH * TW; o += 256) {
+        int r = o / TW, c = o - r * TW, oy = ty0 + r, ox = tx0 + c;
+        if (oy >= oh || ox >= ow) continue;
+        float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float g = G.g[k];
+            mu1 += g * hz[0][r + k][c]; mu2 += g * hz[1][r + k][c]; e11 += g * hz[2][r + k][c];
+            e22 += g * hz[3][r + k][c]; e12 += g * hz[4][r + k][c];
+        }
+        float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        float An = 2.f * s12 + c2, Bd = s11 + s22 + c2, cs = An / Bd;
+        float da = 2.f / Bd, db = -An / (Bd * Bd), dmu = 0.f, val = cs;
+        if (last) {
+            float Ln = 2.f * mu1 * mu2 + c1, Ld = mu1 * mu1 + mu2 * mu2 + c1, l = Ln / Ld;
+            val = l * cs;
+            dmu = cs * (2.f * mu2 * Ld - Ln * 2.f * mu1) / (Ld * Ld);
+            da *= l; db *= l;
+        }
+        size_t mi = ((size_t)q * oh + oy) * ow + ox;
+        mA[mi] = da; mB[mi] = db; mC[mi] = dmu - da * mu2 - 2.f * db * mu1;
+        acc += val;
+    }
+    float r = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(sums + q, r);
+}
+// per-plane product over levels, loss value and upstream scalars (loss_utils.py:196-211).
+// sums: [4][planes] (levels 1..4 are computed, level 0 is the constant 1 of start_level=1);
+// cnt[l] = valid pixels of level l.  scal[l][q] = d(loss)/d(sum_l[q]); loss_out += lambda*(1-mean msssim)
+struct Cnt4 { float c[4]; };
+__global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, Cnt4 cn, float lambda,
+                                  float* __restrict__ scal, float* __restrict__ loss_out) {
+    __shared__ float red[16];
+    const float wgt[4] = {0.2856f, 0.3001f, 0.2363f, 0.1333f};
+    float tot = 0.f;
+    for (int q = threadIdx.x; q < planes; q += blockDim.x) {
+        float v[4], prod = 1.f;
+        for (int l = 0; l < 4; ++l) { v[l] = fmaxf(sums[l * planes + q] / cn.c[l], 0.f); prod *= powf(v[l], wgt[l]); }
+        tot += prod;
+        for (int l = 0; l < 4; ++l)
+            scal[l * planes + q] = v[l] > 0.f ? -lambda / (float)planes * prod * wgt[l] / v[l] / cn.c[l] : 0.f;
+    }
+    float r = block_sum(tot, red);
+    if (threadIdx.x == 0) *loss_out = lambda * (1.f - r / (float)planes);
+}
+// grad wrt X of one level: s * (Y*G^T(a) + 2X*G^T(b) + G^T(c)) + avgpool-backward of the next level's grad
+__global__ __launch_bounds__(256) void k_ssim_bwd(const float* __restrict__ X, const float* __restrict__ Y, int h, int w,
+                                                  const float* __restrict__ mA, const float* __restrict__ mB, const float* __restrict__ mC,
+                                                  const float* __restrict__ scal, Gauss11 G, const float* __restrict__ gnext,
+                                                  int nh, int nw, float* __restrict__ gout) {
+    __shared__ float sm[3][TIH][TIW + 1];
+    __shared__ float hz[3][TIH][TW];
+    const int q = blockIdx.z, oh = h - HALO, ow = w - HALO, tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t mo = (size_t)q * oh * ow;
+    for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
+        int r = i / TIW, c = i - r * TIW, my = ty0 - HALO + r, mx = tx0 - HALO + c;
+        bool in = my >= 0 && my < oh && mx >= 0 && mx < ow;
+        size_t mi = mo + (size_t)my * ow + mx;
+        sm[0][r][c] = in ? mA[mi] : 0.f; sm[1][r][c] = in ? mB[mi] : 0.f; sm[2][r][c] = in ? mC[mi] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TIH * TW; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { float g = G.g[k]; a0 += g * sm[0][r][c + k]; a1 += g * sm[1][r][c + k]; a2 += g * sm[2][r][c + k]; }
+        hz[0][r][c] = a0; hz[1][r][c] = a1; hz[2][r][c] = a2;
+    }
+    __syncthreads();
+    const float s = scal[q];
+    for (int o = threadIdx.x; o < TH * TW; o += 256) {
+        int r = o / TW, c = o - r * TW, y = ty0 + r, x = tx0 + c;
+        if (y >= h || x >= w) continue;
+        float ta = 0, tb = 0, tc = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { float g = G.g[k]; ta += g * hz[0][r + k][c]; tb += g * hz[1][r + k][c]; tc += g * hz[2][r + k][c]; }
+        size_t pi = (size_t)q * h * w + (size_t)y * w + x;
+        float g = s * (Y[pi] * ta + 2.f * X[pi] * tb + tc);
+        if (gnext) g += 0.25f * gnext[(size_t)q * nh * nw + (size_t)((y + (h & 1)) >> 1) * nw + ((x + (w & 1)) >> 1)];
+        gout[pi] = g;
+    }
+}
+
+// ---------------------------------------------------------------- per-pixel losses on `images`
+// gimg[p] = avgpool-backward(grad of level 1) + L1-photometric grad + TV grad; sums -> acc[0..2]
+__global__ void k_pixel_losses(const float* __restrict__ img, const float* __restrict__ tgt, const int* __restrict__ idx,
+                               const float* __restrict__ g1, int h1, int w1, int H, int W, float coef_l1, float coef_tvh,
+                               float coef_tvw, float* __restrict__ gimg, float* __restrict__ acc) {
+    __shared__ float red[16];
+    const int q = blockIdx.y, P = H * W;
+    const float* x = img + (size_t)q * P;
+    const float* t = tgt ? tgt + ((size_t)idx[q / 3] * 3 + q % 3) * P : nullptr;
+    float s_l1 = 0, s_h = 0, s_w = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int y = p / W, xx = p - y * W;
+        float v = x[p];
+        float g = g1 ? 0.25f * g1[(size_t)q * h1 * w1 + (size_t)((y + (H & 1)) >> 1) * w1 + ((xx + (W & 1)) >> 1)] : 0.f;
+        if (coef_l1 != 0.f) {
+            float d = v - t[p];
+            s_l1 += fabsf(d);
+            g += coef_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (coef_tvh != 0.f) {
+            if (y > 0) { float d = v - x[p - W]; s_h += d * d; g += coef_tvh * 2.f * d; }
+            if (y < H - 1) g -= coef_tvh * 2.f * (x[p + W] - v);
+            if (xx > 0) { float d = v - x[p - 1]; s_w += d * d; g += coef_tvw * 2.f * d; }
+            if (xx < W - 1) g -= coef_tvw * 2.f * (x[p + 1] - v);
+        }
+        gimg[(size_t)q * P + p] = g;
+    }
+    float r0 = block_sum(s_l1, red), r1 = block_sum(s_h, red), r2 = block_sum(s_w, red);
+    if (threadIdx.x == 0) {
+        if (coef_l1 != 0.f) atomicAdd(acc + 0, r0);
+        if (coef_tvh != 0.f) { atomicAdd(acc + 1, r1); atomicAdd(acc + 2, r2); }
+    }
+}
+// flow-consistency term (generate.py:420-427): warp(pre)*m vs img*m, fwd + bwd fused.
+// images = cat[0..b), pre = cat[b..2b); gcat same layout.  gimg gets '-=' (owner pixel), gpre atomics.
+__global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
+                            const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gcat,
+                            float* __restrict__ acc) {
+    __shared__ float red[16];
+    const int j = blockIdx.y, f = idx[j], P = H * W;
+    if (f == 0) return;  // valid = idx > 0
+    const float* img = cat + (size_t)j * 3 * P; const float* pre = cat + (size_t)(b + j) * 3 * P;
+    float* gi = gcat + (size_t)j * 3 * P; float* gp = gcat + (size_t)(b + j) * 3 * P;
+    const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
+    float s = 0.f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        int y = p / W, x = p - y * W;
+        Tap t = make_tap(fl[p], fl[P + p], x, y, W, H);
+        float m = mk[p], wv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
+                float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
+                wv[0] += wt * pre[a]; wv[1] += wt * pre[P + a]; wv[2] += wt * pre[2 * P + a];
+            }
+        }
+        float gw[3]; bool any = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = wv[c] * m - img[c * P + p] * m;
+            s += fabsf(d);
+            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * scale;
+            gi[c * P + p] -= gw[c];
+            any |= gw[c] != 0.f;
+        }
+        if (any) {
+            for (int jj = 0; jj < 4; ++jj) {
+                int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
+                for (int i = 0; i < 4; ++i) {
+                    int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
+                    float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
+                    atomicAdd(gp + a, wt * gw[0]); atomicAdd(gp + P + a, wt * gw[1]); atomicAdd(gp + 2 * P + a, wt * gw[2]);
+                }
+            }
+        }
+    }
+    float r = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc + 3, r);
+}
+// loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
+__global__ void k_loss_finalize(float* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
+                                float c_tvh, float c_tvw, float* loss_out) {
+    float l = w_photo * (c_l1 * acc[0] + *ms_term) + w_flow * acc[3] * inv_cnt_flow + c_tvh * acc[1] + c_tvw * acc[2];
+    *loss_out = l;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+}
+
+// ---------------------------------------------------------------- optimiser / init
+// torch.optim.Adam step; g is zeroed for the next iteration's atomics (saves a memset pass).
+__global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                       float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i], mi = b1 * m[i] + (1.f - b1) * gi, vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi; g[i] = 0.f;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+__global__ void k_scatter_accum(const float* __restrict__ img, const int* __restrict__ inv, float* __restrict__ sum,
+                                float* __restrict__ cnt, int P) {
+    const int f = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        size_t id = inv[(size_t)f * P + p];
+        const float* s = img + (size_t)f * 3 * P;
+        atomicAdd(sum + id * 3, s[p]); atomicAdd(sum + id * 3 + 1, s[P + p]); atomicAdd(sum + id * 3 + 2, s[2 * P + p]);
+        atomicAdd(cnt + id, 1.f);
+    }
+}
+__global__ void k_scatter_final(float* __restrict__ feat, const float* __restrict__ cnt, size_t K) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < K * 3; i += (size_t)gridDim.x * blockDim.x)
+        feat[i] = (feat[i] / fmaxf(cnt[i / 3], 1.f) - 0.5f) / SH_C0;  // mean then RGB2SH (generate.py:478-479)
+}
+
+// ================================================================= host side (C ABI)
+static inline dim3 pgrid(int P, int ny) { return dim3(stream_grid(P, 256, 4) > 1024 ? 1024 : stream_grid(P, 256, 4), ny); }
+static inline int pooled(int s) { return (s + 2 * (s & 1) - 2) / 2 + 1; }
+
+extern "C" {
+
+int tcl_warp_flow_fwd(const float* img, const float* flow, float* out, int n, int c, int h, int w, int flow_c, hipStream_t st) {
+    TCL_CHECK_ARG(img && flow && out && n > 0 && c > 0 && h > 1 && w > 1 && flow_c >= 2);
+    hipLaunchKernelGGL(k_warp_fwd, pgrid(h * w, n), dim3(256), 0, st, img, flow, out, c, h, w, flow_c);
+    TCL_LAUNCH_RET();
+}
+int tcl_warp_flow_bwd(const float* gout, const float* flow, float* gimg, int n, int c, int h, int w, int flow_c, hipStream_t st) {
+    TCL_CHECK_ARG(gout && flow && gimg && n > 0 && c > 0 && h > 1 && w > 1 && flow_c >= 2);
+    if (hipMemsetAsync(gimg, 0, (size_t)n * c * h * w * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    hipLaunchKernelGGL(k_warp_bwd, pgrid(h * w, n), dim3(256), 0, st, gout, flow, gimg, c, h, w, flow_c);
+    TCL_LAUNCH_RET();
+}
+int tcl_apply_exposure(const float* src, const int* idx, const float* expo, float* out, int nb, int h, int w, hipStream_t st) {
+    TCL_CHECK_ARG(src && expo && out && nb > 0);
+    hipLaunchKernelGGL(k_apply_exposure, pgrid(h * w, nb), dim3(256), 0, st, src, idx, expo, out, h * w);
+    TCL_LAUNCH_RET();
+}
+int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, hipStream_t st) {
+    TCL_CHECK_ARG(feat && inv && out && nb > 0);
+    hipLaunchKernelGGL(k_gather_codebook, pgrid(h * w, nb), dim3(256), 0, st, feat, inv, fidx, out, h * w);
+    TCL_LAUNCH_RET();
+}
+int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
+    TCL_CHECK_ARG(p && g && m && v && step >= 1);
+    float bc1 = (float)(1.0 - pow((double)b1, step)), bc2 = (float)sqrt(1.0 - pow((double)b2, step));
+    hipLaunchKernelGGL(k_adam, dim3(stream_grid((long)n, 256, 4)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
+    TCL_LAUNCH_RET();
+}
+int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, hipStream_t st) {
+    TCL_CHECK_ARG(img && inv && feat && cnt && K > 0);
+    if (hipMemsetAsync(feat, 0, K * 12, st) != hipSuccess || hipMemsetAsync(cnt, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    hipLaunchKernelGGL(k_scatter_accum, pgrid(h * w, n), dim3(256), 0, st, img, inv, feat, cnt, h * w);
+    hipLaunchKernelGGL(k_scatter_final, dim3(stream_grid((long)K * 3, 256, 4)), dim3(256), 0, st, feat, cnt, K);
+    TCL_LAUNCH_RET();
+}
+
+// workspace carve for the MS-SSIM chain over `planes` planes of h x w
+struct MsWs { float *X[5], *Y[5], *mA[5], *mB[5], *mC[5], *gX[5], *sums, *scal, *cnt, *term; int h[5], w[5]; size_t bytes; };
+static MsWs carve_ms(char* base, int planes, int h, int w) {
+    MsWs W; memset(&W, 0, sizeof(W));
+    size_t off = 0;
+    auto take = [&](size_t nfloat) { float* p = (float*)(base ? base + off : nullptr); off += (nfloat * 4 + 255) & ~(size_t)255; return p; };
+    W.h[0] = h; W.w[0] = w;
+    for (int l = 1; l < 5; ++l) { W.h[l] = pooled(W.h[l - 1]); W.w[l] = pooled(W.w[l - 1]); }
+    for (int l = 1; l < 5; ++l) {
+        size_t n = (size_t)planes * W.h[l] * W.w[l], no = (size_t)planes * (W.h[l] - HALO) * (W.w[l] - HALO);
+        W.X[l] = take(n); W.Y[l] = take(n); W.gX[l] = take(n); W.mA[l] = take(no); W.mB[l] = take(no); W.mC[l] = take(no);
+    }
+    W.sums = take((size_t)4 * planes); W.scal = take((size_t)4 * planes); W.cnt = take(4); W.term = take(1);
+    W.bytes = off;
+    return W;
+}
+size_t tcl_msssim_workspace_bytes(int planes, int h, int w) { return carve_ms(nullptr, planes, h, w).bytes + 256; }
+
+// forward (+ optional backward to level-1 grad) of lambda*(1 - relaxed_ms_ssim(X, Y, start_level=1)).
+// X: [planes] contiguous planes; Y planes addressed through yidx (frame ids, 3 planes per frame) or contiguous.
+static int msssim_chain(const float* X, const float* Y, const int* yidx, int planes, int h, int w, float lambda, MsWs& W,
+                        bool backward, hipStream_t st) {
+    static const Gauss11 G = make_gauss();
+    for (int l = 1; l < 5; ++l) if (W.h[l] < 11 || W.w[l] < 11) return TCL_EINVAL;
+    Cnt4 cn;
+    for (int l = 1; l < 5; ++l) cn.c[l - 1] = (float)(W.h[l] - HALO) * (float)(W.w[l] - HALO);
+    if (hipMemsetAsync(W.sums, 0, (size_t)4 * planes * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    for (int l = 1; l < 5; ++l) {
+        dim3 g(cdiv((long)W.h[l] * W.w[l], 256) > 512 ? 512 : cdiv((long)W.h[l] * W.w[l], 256), planes);
+        hipLaunchKernelGGL(k_pool2, g, dim3(256), 0, st, l == 1 ? X : W.X[l - 1], (const int*)nullptr, W.X[l], W.h[l - 1], W.w[l - 1], W.h[l], W.w[l]);
+        hipLaunchKernelGGL(k_pool2, g, dim3(256), 0, st, l == 1 ? Y : W.Y[l - 1], l == 1 ? yidx : (const int*)nullptr, W.Y[l], W.h[l - 1], W.w[l - 1], W.h[l], W.w[l]);
+        dim3 gs(cdiv(W.w[l] - HALO, TW), cdiv(W.h[l] - HALO, TH), planes);
+        hipLaunchKernelGGL(k_ssim_fwd, gs, dim3(256), 0, st, W.X[l], W.Y[l], W.h[l], W.w[l], l == 4 ? 1 : 0, 0.0001f, 0.0009f, G,
+                           W.mA[l], W.mB[l], W.mC[l], W.sums + (size_t)(l - 1) * planes);
+    }
+    hipLaunchKernelGGL(k_msssim_finalize, dim3(1), dim3(256), 0, st, W.sums, planes, cn, lambda, W.scal, W.term);
+    if (backward)
+        for (int l = 4; l >= 1; --l) {
+            dim3 gs(cdiv(W.w[l], TW), cdiv(W.h[l], TH), planes);
+            hipLaunchKernelGGL(k_ssim_bwd, gs, dim3(256), 0, st, W.X[l], W.Y[l], W.h[l], W.w[l], W.mA[l], W.mB[l], W.mC[l],
+                               W.scal + (size_t)(l - 1) * planes, G, l < 4 ? W.gX[l + 1] : (const float*)nullptr,
+                               l < 4 ? W.h[l + 1] : 0, l < 4 ? W.w[l + 1] : 0, W.gX[l]);
+        }
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+// value = 1 - relaxed_ms_ssim(X, Y, data_range=1, start_level=1); gradX = d(value)/dX (may be null)
+int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, float* value, float* gradX, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(X && Y && value && ws && planes > 0);
+    MsWs W = carve_ms((char*)ws, planes, h, w);
+    int rc = msssim_chain(X, Y, nullptr, planes, h, w, 1.f, W, gradX != nullptr, st);
+    if (rc) return rc;
+    if (gradX) {
+        hipLaunchKernelGGL(k_pixel_losses, pgrid(h * w, planes), dim3(256), 0, st, X, (const float*)nullptr, (const int*)nullptr, W.gX[1],
+                           W.h[1], W.w[1], h, w, 0.f, 0.f, 0.f, gradX, W.term);
+    }
+    if (hipMemcpyAsync(value, W.term, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TCL_ELAUNCH;
+    TCL_LAUNCH_RET();
+}
+
+int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st) {
+    TCL_CHECK_ARG(x && value && grad && ws16 && b > 0);
+    float* acc = (float*)ws16;
+    if (hipMemsetAsync(acc, 0, 16, st) != hipSuccess) return TCL_ELAUNCH;
+    float ch = weight * 2.f / ((float)c * (h - 1) * w) / b, cw = weight * 2.f / ((float)c * h * (w - 1)) / b;
+    hipLaunchKernelGGL(k_pixel_losses, pgrid(h * w, b * c), dim3(256), 0, st, x, (const float*)nullptr, (const int*)nullptr,
+                       (const float*)nullptr, 0, 0, h, w, 0.f, ch, cw, grad, acc);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, acc, acc + 3 /* reads 0 */, 0.f, 0.f, 0.f, 0.f, ch, cw, value);
+    TCL_LAUNCH_RET();
+}
+
+// ---- whole-stage drivers -------------------------------------------------------------------
+struct StageWs { float *cat, *gcat, *acc; int* cidx; MsWs ms; size_t bytes; };
+static StageWs carve_stage(char* base, int b, int h, int w) {
+    StageWs S; size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    size_t P = (size_t)h * w;
+    S.cat = (float*)take(2 * b * 3 * P * 4); S.gcat = (float*)take(2 * b * 3 * P * 4); S.acc = (float*)take(64);
+    S.cidx = (int*)take(2 * b * 4);
+    size_t msb = carve_ms(nullptr, b * 3, h, w).bytes;
+    char* mp = take(msb);
+    S.ms = carve_ms(mp, b * 3, h, w);
+    S.bytes = off;
+    return S;
+}
+size_t tcl_stage_workspace_bytes(int batch, int h, int w) { return carve_stage(nullptr, batch, h, w).bytes + 256; }
+
+static double expon_lr(int step, double lr_init, double lr_final, int max_steps) {  // general_utils.py:31-64, delay off
+    double t = (double)step / max_steps; t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    return exp(log(lr_init) * (1 - t) + log(lr_final) * t);
+}
+
+// Stage 1 (generate.py:354-451).  sched: host int32 [iters][batch] frame ids, -1 pads a short batch;
+// d_cat: packed cat indices on the device.  exposure/m/v/g: [N,3,4] device (exposure = eye, others 0 on entry).
+// losses: device float [iters].  On return (stream order) `edited` holds the aligned frames.
+int tcl_exposure_align(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* sched,
+                       const int* d_cat, int iters, int iters_per_epoch, int batch, int epochs, float lr_init, float lr_final, float lambda_dssim,
+                       float lambda_flow, float* exposure, float* g, float* m, float* v, float* losses, float* aligned_out,
+                       void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(edited && flows && masks && sched && d_cat && exposure && g && m && v && losses && aligned_out && ws);
+    TCL_CHECK_ARG(N > 0 && batch > 0 && iters > 0 && epochs > 0 && iters_per_epoch > 0 && H > 160 && W > 160);
+    StageWs S = carve_stage((char*)ws, batch, H, W);
+    const size_t P = (size_t)H * W;
+    const int total_iters = epochs * N / batch, per_epoch = iters_per_epoch;
+    if (hipMemsetAsync(S.acc, 0, 64, st) != hipSuccess) return TCL_ELAUNCH;
+    for (int it = 0; it < iters; ++it) {
+        const int* bi = sched + (size_t)it * batch;
+        int b = 0, nvalid = 0;
+        while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
+        TCL_CHECK_ARG(b > 0);
+        S.cidx = const_cast<int*>(d_cat) + (size_t)it * 2 * batch;   // [cur(b) | prev(b)] packed for this iteration
+        int epoch = it / per_epoch, i = it % per_epoch;
+        float lr = (float)expon_lr(epoch * N / batch + i + 1, lr_init, lr_final, total_iters);
+        hipLaunchKernelGGL(k_apply_exposure, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.cat, (int)P);
+        const float wp = 1.f - lambda_flow, c_l1 = wp * (1.f - lambda_dssim) / ((float)b * 3 * P);  // (1-lf) folded in
+        int rc = msssim_chain(S.cat, edited, S.cidx, b * 3, H, W, wp * lambda_dssim, S.ms, true, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, edited, S.cidx, S.ms.gX[1], S.ms.h[1], S.ms.w[1], H, W,
+                           c_l1, 0.f, 0.f, S.gcat, S.acc);
+        if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        float inv_cnt = nvalid ? 1.f / ((float)nvalid * 3 * P) : 0.f;
+        hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
+        hipLaunchKernelGGL(k_exposure_bwd, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gcat, g, (int)P);
+        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, c_l1, lambda_flow, inv_cnt, 0.f, 0.f, losses + it);
+        rc = tcl_adam_step(exposure, g, m, v, (size_t)N * 12, lr, 0.9f, 0.999f, 1e-8f, it + 1, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_apply_exposure, pgrid(P, N), dim3(256), 0, st, edited, (const int*)nullptr, exposure, aligned_out, (int)P);
+    TCL_LAUNCH_RET();
+}
+
+// Stage 2 (generate.py:453-533).  feat/g/m/v: [K,3] device (feat initialised by tcl_scatter_mean_rgb2sh, others 0).
+int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
+                          size_t K, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
+                          float lambda_tv, float* feat, float* g, float* m, float* v, float* losses, float* images_out, void* ws,
+                          hipStream_t st) {
+    TCL_CHECK_ARG(target && flows && masks && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
+    TCL_CHECK_ARG(N > 0 && batch > 0 && batch <= 64 && iters >= 0 && H > 160 && W > 160 && K > 0);
+    StageWs S = carve_stage((char*)ws, batch, H, W);
+    const size_t P = (size_t)H * W;
+    const float lr = feature_lr * (float)batch / (float)N;
+    if (hipMemsetAsync(S.acc, 0, 64, st) != hipSuccess) return TCL_ELAUNCH;
+    for (int it = 0; it < iters; ++it) {
+        const int* bi = sched + (size_t)it * batch;
+        int b = 0, nvalid = 0;
+        while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
+        TCL_CHECK_ARG(b > 0);
+        S.cidx = const_cast<int*>(d_cat) + (size_t)it * 2 * batch;
+        hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P);
+        // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
+        int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st);
+        if (rc) return rc;
+        float ch = lambda_tv * 2.f / (3.f * (H - 1) * W) / b, cw = lambda_tv * 2.f / (3.f * H * (W - 1)) / b;
+        hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, (const float*)nullptr, S.cidx, S.ms.gX[1], S.ms.h[1],
+                           S.ms.w[1], H, W, 0.f, ch, cw, S.gcat, S.acc);
+        if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        float inv_cnt = nvalid ? 1.f / ((float)nvalid * 3 * P) : 0.f;
+        hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
+        hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P);
+        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, losses + it);
+        rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
+        if (rc) return rc;
+    }
+    if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P);
+    TCL_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Path 2 host side: the reference's stage-1/2 operator seam on top of the HIP C ABI.
+
+Same names / argument meaning as the reference (SURVEY 8(b) "Stage-1/2 ops"):
+  warp_flow(frames, past_flows)                    utils/flow_utils.py:5
+  relaxed_ms_ssim(X, Y, data_range=1, start_level=1)   utils/loss_utils.py:125
+  TVLoss(weight)(x)                                utils/loss_utils.py:324
+  OptDataset                                       utils/dataloader.py:9
+  exposure_align / unique_tensor_optimization      generate.py:354 / :453
+The three loss ops are torch.autograd.Functions whose forward AND backward are HIP kernels.
+"""
+import numpy as np
+import torch
+
+from .lib import lib, stream, check
+
+F32 = torch.float32
+
+
+class _WarpFlow(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, frames, past_flows):
+        frames = check(frames.contiguous(), F32)
+        flows = check(past_flows.contiguous(), F32)
+        n, c, h, w = frames.shape
+        out = torch.empty_like(frames)
+        lib().tcl_warp_flow_fwd(frames, flows, out, n, c, h, w, flows.shape[1], stream())
+        ctx.save_for_backward(flows)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (flows,) = ctx.saved_tensors
+        gout = check(gout.contiguous(), F32)
+        n, c, h, w = gout.shape
+        gimg = torch.empty_like(gout)
+        lib().tcl_warp_flow_bwd(gout, flows, gimg, n, c, h, w, flows.shape[1], stream())
+        return gimg, None
+
+
+def warp_flow(frames, past_flows):
+    return _WarpFlow.apply(frames, past_flows)
+
+
+class _MsSsim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = check(x.contiguous(), F32), check(y.contiguous(), F32)
+        b, c, h, w = x.shape
+        ws = torch.empty(lib().tcl_msssim_workspace_bytes(b * c, h, w), dtype=torch.uint8, device=x.device)
+        val = torch.empty(1, dtype=F32, device=x.device)
+        grad = torch.empty_like(x) if x.requires_grad else None
+        lib().tcl_ms_ssim_loss(x, y, b * c, h, w, val, grad if grad is not None else 0, ws, stream())
+        ctx.grad = grad
+        return 1.0 - val[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (-g * ctx.grad if ctx.grad is not None else None), None
+
+
+def relaxed_ms_ssim(X, Y, data_range=1, start_level=1):
+    if data_range != 1 or start_level != 1:
+        raise NotImplementedError("HIP relaxed_ms_ssim implements the configuration TC-Light uses "
+                                  "(data_range=1, start_level=1; generate.py:416,510)")
+    if X.shape != Y.shape or X.dim() != 4:
+        raise ValueError(f"Input images should have the same 4-d dimensions, but got {X.shape} and {Y.shape}.")
+    assert min(X.shape[-2:]) > 160, "Image size should be larger than 160 due to the 4 downsamplings in ms-ssim"
+    return _MsSsim.apply(X, Y)
+
+
+class _TV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = check(x.contiguous(), F32)
+        b, c, h, w = x.shape
+        val = torch.empty(1, dtype=F32, device=x.device)
+        grad = torch.empty_like(x)
+        ws = torch.empty(16, dtype=F32, device=x.device)
+        lib().tcl_tv_loss(x, b, c, h, w, float(weight), val, grad, ws, stream())
+        ctx.grad = grad
+        return val[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.grad, None
+
+
+class TVLoss(torch.nn.Module):
+    def __init__(self, TVLoss_weight=1):
+        super().__init__()
+        self.TVLoss_weight = TVLoss_weight
+
+    def forward(self, x):
+        return _TV.apply(x, self.TVLoss_weight)
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+class OptDataset:
+    """utils/dataloader.py:9-42 -- device-resident stage-1/2 inputs."""
+
+    def __init__(self, edited_images, past_flows, mask_bwd, device, dtype=F32):
+        self.edited_images = edited_images.to(dtype=dtype, device=device).contiguous()
+        self.past_flows = past_flows.to(dtype=dtype, device=device).contiguous()
+        self.mask_bwd = mask_bwd.to(dtype=dtype, device=device).contiguous()
+        if self.edited_images.max() > 1:
+            self.edited_images = self.edited_images / 255.0
+        self.device, self.dtype = device, dtype
+
+    def __len__(self):
+        return len(self.edited_images)
+
+
+def make_schedule(n, batch_size, epochs, rng):
+    """Stand-in for DataLoader(shuffle=True): host int32 [iters, batch] (-1 padded) from a numpy Generator."""
+    rows = []
+    for _ in range(epochs):
+        p = rng.permutation(n)
+        for i in range(0, n, batch_size):
+            r = np.full(batch_size, -1, np.int32)
+            c = p[i:i + batch_size]
+            r[:len(c)] = c
+            rows.append(r)
+    return np.stack(rows)
+
+
+def _pack_schedule(batches, batch_size, device):
+    """list of index tensors / [iters,batch] array -> (host sched int32, device cat int32 [iters, 2*batch])."""
+    if isinstance(batches, np.ndarray):
+        sched = np.ascontiguousarray(batches, dtype=np.int32)
+    else:
+        sched = np.full((len(batches), batch_size), -1, np.int32)
+        for i, b in enumerate(batches):
+            sched[i, :len(b)] = np.asarray(b, dtype=np.int32)
+    cat = np.zeros((sched.shape[0], 2 * batch_size), np.int32)
+    for i, r in enumerate(sched):
+        cur = r[r >= 0]
+        cat[i, :len(cur)] = cur
+        cat[i, len(cur):2 * len(cur)] = np.maximum(cur - 1, 0)
+    return sched, torch.from_numpy(cat).to(device)
+
+
+def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_final=0.001,
+                   lambda_dssim=0.2, lambda_flow=0.8, iters_per_epoch=None):
+    """generate.py:354-451.  Returns (aligned images, exposure [N,3,4], losses tensor) and bakes the
+    alignment into dataset.edited_images like OptDataset.exposure_align does."""
+    ed = dataset.edited_images
+    n, _, h, w = ed.shape
+    dev = ed.device
+    sched, d_cat = _pack_schedule(batches, batch_size, dev)
+    if iters_per_epoch is None:
+        iters_per_epoch = -(-n // batch_size)      # len(DataLoader)
+    expo = torch.eye(3, 4, device=dev)[None].repeat(n, 1, 1).contiguous()
+    g, m, v = (torch.zeros_like(expo) for _ in range(3))
+    losses = torch.zeros(len(sched), device=dev)
+    out = torch.empty_like(ed)
+    ws = torch.empty(lib().tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
+    lib().tcl_exposure_align(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, sched.ctypes.data, d_cat, len(sched),
+                             iters_per_epoch, batch_size, epochs, lr_init, lr_final, lambda_dssim, lambda_flow, expo, g, m, v, losses,
+                             out, ws, stream())
+    dataset.edited_images = out
+    return out, expo, losses
+
+
+def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature_lr=0.05, lambda_dssim=0.2,
+                               lambda_flow=0.8, lambda_tv=0.05, k=None):
+    """generate.py:453-533.  unq_inv: [N*H*W] integer tensor on the device.  Returns (images, features_dc, losses)."""
+    ed = dataset.edited_images
+    n, _, h, w = ed.shape
+    dev = ed.device
+    inv = unq_inv.to(device=dev, dtype=torch.int32).contiguous()
+    if k is None:
+        k = int(inv.max()) + 1
+    sched, d_cat = _pack_schedule(batches, batch_size, dev)
+    feat = torch.empty(k, 3, device=dev)
+    cnt = torch.empty(k, device=dev)
+    lib().tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, stream())
+    del cnt
+    g, m, v = (torch.zeros_like(feat) for _ in range(3))
+    losses = torch.zeros(max(len(sched), 1), device=dev)
+    out = torch.empty_like(ed)
+    ws = torch.empty(lib().tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
+    lib().tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, sched.ctypes.data, d_cat,
+                                len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
+                                losses, out, ws, stream())
+    return out, feat, losses[:len(sched)]

@@ -1,0 +1,129 @@
+"""GPU parity tests for path 2: HIP kernels (through the C ABI) vs the CPU oracle and the reference goldens.
+
+Tolerances (fp32 path): losses rel 2e-5; images / parameters abs 2e-5 after a few Adam steps; single-op
+outputs abs 1e-5.  Sums use float atomics, so results are order-dependent at the 1e-7 relative level.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd import post_opt
+    return post_opt
+
+
+def sub(t, k=97):
+    return t.detach().cpu().reshape(-1)[::k].numpy()
+
+
+def test_warp_flow_fwd_bwd(ops, golden):
+    from oracle import path2 as O
+    g = golden("path2")
+    d = synth.video_clip(4, 176, 192, seed=11)
+    ed, fl = d["edited"], d["past_flows"] * 3.0
+    x = ed.cuda().requires_grad_(True)
+    out = ops.warp_flow(x, fl.cuda())
+    gsel = torch.from_numpy(np.random.default_rng(5).standard_normal(out.shape).astype(np.float32))
+    (out * gsel.cuda()).sum().backward()
+    np.testing.assert_allclose(sub(out), g["warp_fwd"], atol=2e-6)          # vs reference golden
+    np.testing.assert_allclose(sub(x.grad), g["warp_grad"], atol=2e-5)
+    xo = ed.clone().requires_grad_(True)                                      # vs oracle, every element
+    oo = O.warp_flow(xo, fl)
+    (oo * gsel).sum().backward()
+    assert (out.cpu() - oo).abs().max() < 2e-6
+    assert (x.grad.cpu() - xo.grad).abs().max() < 2e-5
+    # flows pushing samples out of the image (zeros padding), 2-channel + extra channels in the flow tensor
+    big = torch.cat([fl * 40, torch.ones(4, 1, 176, 192)], 1)
+    o2 = ops.warp_flow(ed.cuda(), big.cuda()).cpu()
+    assert (o2 - O.warp_flow(ed, big)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("hw", [(176, 192), (181, 203)])
+def test_ms_ssim_tv(ops, golden, hw):
+    import torch.nn.functional as F
+    from oracle import path2 as O
+    g = golden("path2")
+    ed = synth.video_clip(4, 176, 192, seed=11)["edited"]
+    hh, ww = hw
+    tag = "a" if hh == 176 else "b"
+    xa = ed[:2] if hh == 176 else F.interpolate(ed[:2], size=hw, mode="bilinear")
+    ya = (xa * 0.9 + 0.05).clamp(0, 1) + 0.02 * torch.from_numpy(
+        np.random.default_rng(6).standard_normal(xa.shape).astype(np.float32))
+    x = xa.clone().cuda().requires_grad_(True)
+    v = ops.relaxed_ms_ssim(x, ya.cuda(), data_range=1, start_level=1)
+    v.backward()
+    assert abs(float(v) - float(g[f"msssim_{tag}"])) < 5e-6
+    np.testing.assert_allclose(sub(x.grad), g[f"msssim_{tag}_grad"], atol=2e-9, rtol=2e-3)
+    xo = xa.clone().requires_grad_(True)
+    O.relaxed_ms_ssim(xo, ya).backward()
+    rel = (x.grad.cpu() - xo.grad).norm() / xo.grad.norm()
+    assert rel < 1e-4, rel
+    if hh == 176:
+        xt = ed[:2].clone().cuda().requires_grad_(True)
+        tv = ops.TVLoss(0.05)(xt)
+        tv.backward()
+        assert abs(float(tv) - float(g["tv"])) < 1e-8
+        np.testing.assert_allclose(sub(xt.grad), g["tv_grad"], atol=1e-10, rtol=1e-4)
+
+
+def test_known_answer_msssim(ops, golden):
+    g = golden("path2")
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 200, 208)
+    y = (x + 0.05 * torch.randn_like(x)).clamp(0, 1)
+    assert abs(float(ops.relaxed_ms_ssim(x.cuda(), y.cuda())) - float(g["ka_msssim"])) < 5e-6
+    assert abs(float(ops.TVLoss(0.05)(x.cuda().requires_grad_(True))) - float(g["ka_tv"])) < 1e-7
+
+
+def test_stage1_stage2_vs_golden_and_oracle(ops, golden):
+    from oracle import path2 as O
+    g = golden("path2")
+    d = synth.video_clip(4, 176, 192, seed=11)
+    n, bs = 4, 2
+    bts = synth.batches(n, bs, epochs=2, seed=7)[:3]
+    ds3 = ops.OptDataset(d["edited"], d["past_flows"], d["masks"], device="cuda")
+    _, expo3, l3 = ops.exposure_align(ds3, bts, epochs=2, batch_size=bs)      # 3 of the 2x2 iterations, as the golden
+    np.testing.assert_allclose(l3.cpu().numpy(), g["s1_losses"], rtol=2e-5)
+    np.testing.assert_allclose(expo3.cpu().numpy(), g["s1_exposure"], atol=2e-5)
+    np.testing.assert_allclose(sub(ds3.edited_images), g["s1_images"], atol=2e-5)
+    # stage 2 vs golden
+    inv, k = synth.track_ids(n, 176, 192, seed=3)
+    ds2 = ops.OptDataset(d["edited"], d["past_flows"], d["masks"], device="cuda")
+    out, feat, l2 = ops.unique_tensor_optimization(ds2, inv.cuda(), bts, batch_size=bs)
+    np.testing.assert_allclose(l2.cpu().numpy(), g["s2_losses"], rtol=2e-5)
+    np.testing.assert_allclose(feat.cpu().reshape(-1)[::31].numpy(), g["s2_feats"], atol=5e-5)
+    oimg, ofeat, _ = O.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, bs)
+    assert (out.cpu() - oimg).abs().max() < 5e-5
+
+
+def test_full_size_properties(ops):
+    """Config-(2)-sized checks through size-independent properties (the oracle would take minutes here)."""
+    h, w = 720, 960
+    d = synth.video_clip(3, h, w, seed=5)
+    ed = d["edited"].cuda()
+    zero = torch.zeros(3, 2, h, w, device="cuda")
+    assert (ops.warp_flow(ed, zero) - ed).abs().max() < 1e-6                 # identity flow
+    shift = zero.clone(); shift[:, 0] = 3.0                                  # integer shift = exact gather
+    ws = ops.warp_flow(ed, shift)
+    assert (ws[..., :-3] - ed[..., 3:]).abs().max() < 1e-6 and ws[..., -1].abs().max() == 0
+    a, b = torch.rand(3, 3, h, w, device="cuda"), torch.rand(3, 3, h, w, device="cuda")
+    lin = ops.warp_flow(2 * a - 3 * b, d["past_flows"].cuda()) - (2 * ops.warp_flow(a, d["past_flows"].cuda()) - 3 * ops.warp_flow(b, d["past_flows"].cuda()))
+    assert lin.abs().max() < 1e-4                                            # linearity in the image
+    assert abs(float(ops.relaxed_ms_ssim(ed, ed)) - 1.0) < 1e-5               # identical images -> 1
+    x = ed.clone().requires_grad_(True)
+    ops.relaxed_ms_ssim(x, ed).backward()
+    assert x.grad.abs().max() < 1e-6                                          # and a stationary point
+    assert float(ops.TVLoss(0.05)(torch.full((2, 3, h, w), 0.3, device="cuda").requires_grad_(True))) == 0.0
+    # Adam / codebook round trip: gather(scatter_mean(images)) with unique ids is the identity
+    inv = torch.arange(3 * h * w, device="cuda", dtype=torch.int32)
+    ds = ops.OptDataset(ed, d["past_flows"], d["masks"], device="cuda")
+    out, feat, _ = ops.unique_tensor_optimization(ds, inv, np.zeros((0, 2), np.int32), batch_size=2, k=3 * h * w)
+    assert (out - ed).abs().max() < 1e-6

@@ -118,12 +118,16 @@ def golden_path2(R):
     n, _, h, w = ed.shape
     bs = 2
     bts = synth.batches(n, bs, epochs=2, seed=7)[:3]
+    # Stage 1 is ill-conditioned for frame 0 as a *current* frame: with exposure = I its only gradient is the
+    # rounding noise of MS-SSIM(X, X) (~1e-9), which Adam (eps 1e-8) turns into a ~1e-3 step of noise-determined
+    # sign.  The pinned schedule therefore keeps frame 0 out of the current slots (it still appears as `pre`).
+    bts1 = [torch.tensor(b) for b in ([2, 1], [3, 2], [1, 3])]
     ds = dl.OptDataset(ed.clone(), fl, mk, device="cpu")
     expo = torch.nn.Parameter(torch.eye(3, 4)[None].repeat(n, 1, 1))
     opt = torch.optim.Adam([expo])
     lr_fn = gu.get_expon_lr_func(0.01, 0.001, lr_delay_steps=0, lr_delay_mult=0.0, max_steps=2 * n // bs)
     losses = []
-    for it, idx in enumerate(bts):
+    for it, idx in enumerate(bts1):
         epoch, i = divmod(it, n // bs)
         for pg in opt.param_groups:
             pg["lr"] = lr_fn(epoch * n // bs + i + 1)

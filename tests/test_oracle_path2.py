@@ -69,8 +69,9 @@ def test_stage1_stage2_three_iterations(golden):
     ed, fl, mk = d["edited"], d["past_flows"], d["masks"]
     n, bs = 4, 2
     bts = synth.batches(n, bs, epochs=2, seed=7)[:3]
+    bts1 = [torch.tensor(b) for b in ([2, 1], [3, 2], [1, 3])]   # see make_golden.py: frame 0 never 'current'
     # oracle's loop wants len(batches) % epochs == 0 for the lr index; emulate 2 epochs of 2 iters
-    img, expo, losses = _stage1(ed, fl, mk, bts, n, bs)
+    img, expo, losses = _stage1(ed, fl, mk, bts1, n, bs)
     np.testing.assert_allclose(losses, g["s1_losses"], rtol=2e-6)
     np.testing.assert_allclose(expo.numpy(), g["s1_exposure"], atol=2e-6)
     np.testing.assert_allclose(sub(img), g["s1_images"], atol=2e-6)

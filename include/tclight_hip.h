@@ -63,6 +63,67 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
                           float lambda_flow, float lambda_tv, float* feat, float* g, float* m, float* v, float* losses,
                           float* images_out, void* ws, hipStream_t st);
 
+/* ===================================================================== path 1: denoising loop (f16, f32 accumulate)
+ * Activations are NHWC / token-major [B, H*W, C] f16 on the device.  These replace the library kernels the reference
+ * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0, lda % 8 == 0.
+ * torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL. */
+int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldc,
+                 int ldr, int act, hipStream_t st);
+/* 3x3 Conv2d as implicit GEMM on NHWC: X [B,Hin,Win,Cin], W [Cout, 9*Cin] (tap-major: (ky*3+kx)*Cin + c), Y [B,Hout,Wout,Cout].
+ * pad=1: padding 1 (UNet ResnetBlock2D / Downsample2D stride 2); pad=0 with stride 2: the VAE encoder's (0,1,0,1) padding.
+ * Hup/Wup > 0: the input is first nearest-upsampled to Hup x Wup (Upsample2D with explicit output size), fused in the gather. */
+int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* resid, void* Y, int B, int Hin, int Win, int Cin,
+                    int Cout, int stride, int pad, int Hup, int Wup, int act, hipStream_t st);
+
+/* torch.nn.GroupNorm(groups, C1+C2, eps) [+ SiLU] over x = cat([x1, x2], channel) (x2 may be NULL with C2 = 0): the
+ * ResnetBlock2D / Transformer2DModel / AutoencoderKL norms, with the up-block skip concat folded in.  y [B,HW,C1+C2]. */
+size_t tcl_groupnorm_workspace_bytes(int B, int C);
+int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
+                      int groups, float eps, int silu, void* ws, hipStream_t st);
+/* torch.nn.LayerNorm(C) (BasicTransformerBlock.norm1/2/3). */
+int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st);
+/* diffusers GEGLU: in [rows, 2D] -> out [rows, D] = in[:, :D] * gelu(in[:, D:]) (exact erf gelu). */
+int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st);
+/* in-place softmax(scale * x) over rows of length T (VAE mid-block single-head attention). */
+int tcl_softmax_rows_f16(void* x, long rows, int T, int ld, float scale, hipStream_t st);
+int tcl_concat_channels_f16(const void* x1, int C1, const void* x2, int C2, void* y, long rows, hipStream_t st);
+/* im2col for 3x3/pad-1 convs with tiny Cin (IC-Light conv_in 8->320, utils/model_utils.py:21-26; VAE 3->128, 4->512). */
+int tcl_im2col3x3_small_f16(const void* x, void* out, int B, int H, int W, int Cin, int Kpad, hipStream_t st);
+/* y = f16(act_out(W . act_in(x) + bias)) + add : time_embedding MLP and ResnetBlock2D.time_emb_proj (M = 1). */
+int tcl_gemv_f16(const void* W, const void* x, const void* bias, const void* add, void* y, int N, int K, int silu_in, int silu_out, hipStream_t st);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]. */
+int tcl_timestep_embed_f16(float t, int dim, void* out, hipStream_t st);
+/* Generator.pred_noise input assembly (generate.py:295-298 + model_utils.py:35-40): latents x / concat_conds [N,4,h,w] f16 ->
+ * UNet input [2F,H',W',8] NHWC.  mode 0: xy-plane, idx = frame ids; mode 1: yt-plane ('n c h w -> w c n h', generate.py:267),
+ * idx = latent columns, frames sl..sl+nwin. */
+int tcl_pack_latents_f16(const void* x, const void* cond, const int* idx, int F, int mode, int sl, int nwin, int h, int w, void* out, hipStream_t st);
+/* CFG combine uncond + g*(cond - uncond) (generate.py:349-350) scattered back to noises[N,4,h,w]; in mode 1 frames
+ * n < scale_upto are multiplied by `scale` (the sqrt(0.5) overlap rule, generate.py:276-278). */
+int tcl_unpack_cfg_f16(const void* eps, const int* idx, int F, int mode, int sl, int nwin, int h, int w, float guidance, int scale_upto,
+                       float scale, void* noise, hipStream_t st);
+/* noises_t <- AdaIN(noises_t, noises); noises <- sqrt(a)*noises_t + sqrt(1-a)*noises  (generate.py:281-282,
+ * utils/general_utils.py:137-156).  planes = N*4, hw = h*w. */
+int tcl_adain_fuse_f16(void* noises_t, void* noises, int planes, int hw, float alpha, hipStream_t st);
+/* DPMSolverMultistepScheduler.step, sde-dpmsolver++ (generate.py:235): m0 <- x0 = (x - sigma_t*eps)/alpha_t;
+ * x <- ca*x + cb0*m0 + cb1*m1 + cc*z (coefficients from tc_light_amd/scheduler.py; f32 math; m1/z may be NULL). */
+int tcl_dpm_sde_step_f16(void* x, const void* eps, float* m0, const float* m1, const void* z, long n, float sigma_t, float alpha_t, float ca,
+                         float cb0, float cb1, float cc, hipStream_t st);
+/* layout conversions around the VAE (generate_utils.py:140-172): 2*img-1 -> NHWC8 f16; clamp(y/2+0.5) -> [B,3,H,W] f32. */
+int tcl_img_to_nhwc8_f16(const float* img, void* out, int B, int HW, hipStream_t st);
+int tcl_nhwc_to_img_f32(const void* y, int ldc, float* img, int B, int HW, hipStream_t st);
+int tcl_nhwc_to_nchw_f16(const void* y, int ldc, void* out, int B, int C, int HW, float scale, hipStream_t st);
+int tcl_nchw_to_nhwc_f16(const void* x, void* out, int ldc, int B, int C, int HW, float scale, hipStream_t st);
+int tcl_transpose_f16(const void* in, void* out, int batch, int R, int Cc, int ldi, int ldo, hipStream_t st);
+
+/* softmax(Q K^T * scale) V per head, flash style (torch SDPA / xformers via AttnProcessor2_0: attn1 on the VidToMe-merged
+ * tokens, patch.py:170-176, and attn2 text cross-attention).  q/k/v/o point at head 0 of batch 0 with heads interleaved
+ * in channels (head hh = channels [hh*d, (hh+1)*d)); ld* row strides and *bs batch strides in halves; d in {40, 80, 160}.
+ * K/V batch = b / kv_div.  pack_kv = 0 reuses the K/V panels a previous call left in ws (text K/V are constant per run). */
+size_t tcl_attention_workspace_bytes(int Bq, int Bkv, int H, int Tq, int Tk, int d);
+int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
+                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws, hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,236 @@
+// Flash attention forward for gfx950 (f16 in, f32 softmax/accumulate), head_dim 40 / 80 / 160 (SD-1.5 UNet) --
+// the self-attention over VidToMe-merged tokens (T up to ~47k) and the text cross-attention that the reference runs
+// through torch SDPA / xformers (AttnProcessor2_0, utils/model_utils.py:66-67; patch.py:170-176).  T x T scores are
+// never materialised.
+//
+// Two kernels:
+//  pack : Q,K,V rows (heads interleaved in channels) -> head-major, zero-padded panels
+//           Qp [B,H,Tqp,DP] (pre-scaled by softmax_scale*log2 e), Kp [B,H,Tkp,DP], Vt [B,H,DPV,Tkp] (V transposed so the
+//           PV contraction reads keys contiguously).  DP = d rounded to 16, DPV = d rounded to 32.
+//  flash: block = 4 waves x 32 query rows; 64-key K/V tiles staged global->VGPR->LDS, double-buffered.
+//         S^T = K.Q^T with mfma_f32_32x32x16_f16 (swapped operands: lane l owns query l&31, so the row max/sum is
+//         in-lane + one lane<->lane+32 exchange); P stays in registers as the B operand of O^T = V^T.P^T (the key
+//         permutation of the accumulator layout is matched by the V^T fragment addresses instead of shuffling P).
+//         Block id -> head = id % H so that each head's K/V panel lives in one XCD's L2.
+#include "common.h"
+#include "../../include/tclight_hip.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#define KV_TILE 64
+#define V_STRIDE 68   // halves: 34 dwords -> the 32 rows of a ds_read_b64 group hit 32 distinct even bank pairs
+
+__global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
+                            _Float16* __restrict__ dst, int Tp, int DP, long total_chunks) {
+    const int cpr = DP / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % cpr) * 8; long row = i / cpr; int t = (int)(row % Tp); long bh = row / Tp; int h = (int)(bh % H); long b = bh / H;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+        if (t < T && c8 < d) {
+            v = *(const half8*)(src + b * bstride + (long)t * ld + h * d + c8);
+            if (scale != 1.f)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] * scale);
+        }
+        *(half8*)(dst + i * 8) = v;
+    }
+}
+// Vt[b][h][i][t] = V[b][t][h*d + i]; one block per (64 tokens, b*h)
+__global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
+                                                 _Float16* __restrict__ vt, int Tp, int DPV) {
+    extern __shared__ _Float16 tile[];   // [64][DPV+2]
+    const int t0 = blockIdx.x * 64, bh = blockIdx.y, h = bh % H; const long b = bh / H;
+    const int st = DPV + 2, cpr = DPV / 8;
+    for (int i = threadIdx.x; i < 64 * cpr; i += 256) {
+        int r = i / cpr, c8 = (i % cpr) * 8, t = t0 + r;
+        half8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (_Float16)0.f;
+        if (t < T && c8 < d) x = *(const half8*)(v + b * bstride + (long)t * ld + h * d + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[r * st + c8 + j] = x[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DPV * 64; i += 256) {
+        int dd = i / 64, r = i % 64;
+        vt[((long)bh * DPV + dd) * Tp + t0 + r] = tile[r * st + dd];
+    }
+}
+
+template <int DP, int DPV>
+__global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                               _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
+                                               int kv_div, int nqb) {
+    constexpr int KS = DP + 8;                    // K row stride (halves); (DP+8)/8 odd -> conflict-free b128 reads
+    constexpr int NQK = DP / 16, NDT = DPV / 32;
+    constexpr int KCH = KV_TILE * DP / 8, VCH = DPV * 8;           // 16-B chunks per tile
+    constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Ks = (_Float16*)smem;                         // [2][64][KS]
+    _Float16* Vs = Ks + 2 * KV_TILE * KS;                   // [2][DPV][V_STRIDE]
+
+    const int bid = blockIdx.x, head = bid % H, qb = (bid / H) % nqb, b = bid / (H * nqb);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hl = lane >> 5, ql = lane & 31;
+    const int q0 = qb * 128 + wid * 32;
+    const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
+    const _Float16* kbase = Kp + kbh * Tkp * DP;
+    const _Float16* vbase = Vt + kbh * DPV * Tkp;
+
+    half8 qf[NQK];
+    {
+        const _Float16* qrow = Qp + (bh * Tqp + q0 + ql) * DP + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NQK; ++ks) qf[ks] = *(const half8*)(qrow + ks * 16);
+    }
+    uint4 rk[KIT], rv[VIT];
+    auto gload = [&](int it) {
+        const _Float16* kt = kbase + (long)it * KV_TILE * DP;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if (c < KCH) rk[i] = *(const uint4*)(kt + c * 8); }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) { int c = tid + 256 * i; if (c < VCH) rv[i] = *(const uint4*)(vbase + (long)(c >> 3) * Tkp + it * KV_TILE + (c & 7) * 8); }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if (c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(uint4*)(Ks + (buf * KV_TILE + r) * KS + c8) = rk[i]; } }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            int c = tid + 256 * i;
+            if (c < VCH) { uint2* p = (uint2*)(Vs + (buf * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p[0] = make_uint2(rv[i].x, rv[i].y); p[1] = make_uint2(rv[i].z, rv[i].w); }
+        }
+    };
+
+    float16v o[NDT];
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -1e30f, lsum = 0.f;
+
+    const int nt = Tkp / KV_TILE;
+    gload(0); sstore(0);
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nt) gload(it + 1);
+        // ---- S^T = K . Q^T  (two 32-key blocks)
+        float16v s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+            const _Float16* kr = Ks + (cur * KV_TILE + blk * 32 + ql) * KS + 8 * hl;
+#pragma unroll
+            for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(kr + ks * 16), qf[ks], s[blk], 0, 0, 0);
+        }
+        if ((it + 1) * KV_TILE > Tk) {   // mask padded keys (last tile only)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
+        }
+        // ---- online softmax (this lane: one query, 32 of the tile's 64 keys; partner lane^32 holds the rest)
+        float mx = s[0][0];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+        half8 pf[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - mn); ps += p; pf[blk][r >> 3][r & 7] = (_Float16)p; }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const _Float16* vr = Vs + (cur * DPV + ql) * V_STRIDE + blk * 32 + 16 * ss + 4 * hl;
+#pragma unroll
+                for (int t = 0; t < NDT; ++t) {
+                    half4 lo = *(const half4*)(vr + t * 32 * V_STRIDE), hi = *(const half4*)(vr + t * 32 * V_STRIDE + 8);
+                    half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][ss], o[t], 0, 0, 0);
+                }
+            }
+        if (it + 1 < nt) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.f / lsum;
+    const int q = q0 + ql;
+    if (q < Tq) {
+        _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int dd = t * 32 + 8 * g + 4 * hl;
+                if (dd < d) {
+                    half4 w = {(_Float16)(o[t][4 * g] * inv), (_Float16)(o[t][4 * g + 1] * inv), (_Float16)(o[t][4 * g + 2] * inv), (_Float16)(o[t][4 * g + 3] * inv)};
+                    *(half4*)(orow + dd) = w;
+                }
+            }
+    }
+}
+
+template <int DP, int DPV>
+static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
+                        int d, int ldo, long obs, int kv_div, hipStream_t st) {
+    const size_t lds = (size_t)2 * KV_TILE * (DP + 8) * 2 + (size_t)2 * DPV * V_STRIDE * 2;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_flash<DP, DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / 128;
+    hipLaunchKernelGGL((k_flash<DP, DPV>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" {
+
+// panel sizes: Tqp = ceil128(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d)
+size_t tcl_attention_workspace_bytes(int Bq, int Bkv, int H, int Tq, int Tk, int d) {
+    size_t q = (size_t)Bq * H * rup(Tq, 128) * rup(d, 16), k = (size_t)Bkv * H * rup(Tk, 64) * rup(d, 16), v = (size_t)Bkv * H * rup(d, 32) * rup(Tk, 64);
+    return (q + k + v) * 2 + 1024;
+}
+
+// softmax(Q K^T * scale) V per head.  q/k/v point at head 0 of batch 0; row strides ld* and batch strides *bs in halves.
+// K/V batch index = b / kv_div (kv_div = F for the text cross-attention whose context repeats per frame, else 1).
+// pack_kv = 0 reuses the K/V panels already in ws (same Bkv, H, Tk, d as the call that packed them).
+int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
+                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(q && o && ws && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
+    TCL_CHECK_ARG(d == 40 || d == 80 || d == 160);
+    TCL_CHECK_ARG(!pack_kv || (k && v));
+    const int Tqp = rup(Tq, 128), Tkp = rup(Tk, 64), DP = rup(d, 16), DPV = rup(d, 32), Bkv = B / kv_div;
+    _Float16* Qp = (_Float16*)ws;
+    _Float16* Kp = Qp + (size_t)B * H * Tqp * DP;
+    _Float16* Vt = Kp + (size_t)Bkv * H * Tkp * DP;
+    long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (DP / 8);
+    hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,
+                       scale * 1.4426950408889634f, Qp, Tqp, DP, qc);
+    if (pack_kv) {
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, DP, kc);
+        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp, DPV);
+    }
+    if (d == 40) return launch_flash<48, 64>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 80) return launch_flash<80, 96>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    return launch_flash<160, 160>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+}
+
+}  // extern "C"

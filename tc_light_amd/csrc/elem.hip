@@ -1,0 +1,415 @@
+// HBM-bound f16 kernels of path 1 (gfx950): GroupNorm(+SiLU), LayerNorm, GEGLU, row softmax, channel concat,
+// small-Cin im2col, GEMV (time embedding), latent pack/unpack with classifier-free guidance, AdaIN + noise fusion,
+// SDE-DPM-Solver++ update, image<->latent layout conversion.  All loads/stores are 16 B per lane (8 halves).
+// Reference call sites: UNet/VAE norms via diffusers (generate.py:342-347); pred_noise generate.py:288-352;
+// temporal_denoise :241-284; adaptive_instance_normalization utils/general_utils.py:137-156;
+// scheduler.step generate.py:235; encode/decode_latents utils/VidToMe/generate_utils.py:140-172.
+#include "common.h"
+#include "../../include/tclight_hip.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// pass 1: per-(batch, group) sum / sumsq.  x = [x1 | x2] concatenated on channels (x2 may be null).
+__global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
+                                                  int HW, int G, int rows_per_block, float* __restrict__ ws) {
+    __shared__ float gs[64], gq[64];
+    const int b = blockIdx.y, C = C1 + C2, cpg = C / G, nchunk = C / 8;
+    if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    const long total = (long)(r1 - r0) * nchunk;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        int row = r0 + (int)(i / nchunk), ch = (int)(i % nchunk) * 8;
+        const _Float16* p = ch < C1 ? x1 + ((long)b * HW + row) * C1 + ch : x2 + ((long)b * HW + row) * C2 + (ch - C1);
+        h8 v = *(const h8*)p;
+        int g0 = ch / cpg; float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int g = (ch + j) / cpg;
+            if (g != g0) { atomicAdd(&gs[g0], s); atomicAdd(&gq[g0], q); g0 = g; s = q = 0.f; }
+            float f = (float)v[j]; s += f; q += f * f;
+        }
+        atomicAdd(&gs[g0], s); atomicAdd(&gq[g0], q);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) { atomicAdd(ws + ((long)b * G + threadIdx.x) * 2, gs[threadIdx.x]); atomicAdd(ws + ((long)b * G + threadIdx.x) * 2 + 1, gq[threadIdx.x]); }
+}
+// pass 2a: per-(batch, channel) scale/shift
+__global__ void k_gn_coef(const float* __restrict__ ws, const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, int C,
+                          int G, float n, float eps, float* __restrict__ coef) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int g = c / (C / G);
+    float mean = ws[((long)b * G + g) * 2] / n, var = ws[((long)b * G + g) * 2 + 1] / n - mean * mean;
+    float rstd = rsqrtf(fmaxf(var, 0.f) + eps), ga = (float)gamma[c];
+    coef[((long)b * C + c) * 2] = rstd * ga;
+    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - mean * rstd * ga;
+}
+// pass 2b: y = act(x*scale + shift), also materialises the channel concat
+__global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
+                                                  const float* __restrict__ coef, _Float16* __restrict__ y, int HW, int silu) {
+    const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8;
+    const long total = (long)HW * nchunk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long row = i / nchunk; int ch = (int)(i % nchunk) * 8;
+        const _Float16* p = ch < C1 ? x1 + ((long)b * HW + row) * C1 + ch : x2 + ((long)b * HW + row) * C2 + (ch - C1);
+        h8 v = *(const h8*)p, o;
+        const float4* cf = (const float4*)(coef + ((long)b * C + ch) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 c4 = cf[j];
+            float a = (float)v[2 * j] * c4.x + c4.y, bb = (float)v[2 * j + 1] * c4.z + c4.w;
+            if (silu) { a = a / (1.f + __expf(-a)); bb = bb / (1.f + __expf(-bb)); }
+            o[2 * j] = (_Float16)a; o[2 * j + 1] = (_Float16)bb;
+        }
+        *(h8*)(y + ((long)b * HW + row) * C + ch) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ __launch_bounds__(256) void k_layernorm(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
+                                                   const _Float16* __restrict__ beta, _Float16* __restrict__ y, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C / 8;
+    h8 v[4]; float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int ch = lane + 64 * k;
+        if (ch < nchunk) { v[k] = *(const h8*)(x + row * C + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[k][j]; }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < nchunk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = (float)v[k][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int ch = lane + 64 * k;
+        if (ch < nchunk) {
+            h8 g = *(const h8*)(gamma + ch * 8), bt = *(const h8*)(beta + ch * 8), o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[k][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
+            *(h8*)(y + row * C + ch * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GEGLU: out = a * gelu(gate)
+__global__ void k_geglu(const _Float16* __restrict__ in, _Float16* __restrict__ out, long rows, int D) {
+    const int nchunk = D / 8;
+    const long total = rows * nchunk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / nchunk; int ch = (int)(i % nchunk) * 8;
+        h8 a = *(const h8*)(in + r * 2 * D + ch), g = *(const h8*)(in + r * 2 * D + D + ch), o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float gf = (float)g[j]; o[j] = (_Float16)((float)a[j] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+        *(h8*)(out + r * D + ch) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ row softmax (in place, scaled)
+__global__ __launch_bounds__(256) void k_softmax_rows(_Float16* __restrict__ x, int T, int ld, float scale) {
+    extern __shared__ float rowbuf[];
+    __shared__ float red[16];
+    _Float16* p = x + (long)blockIdx.x * ld;
+    float mx = -1e30f;
+    for (int i = threadIdx.x; i < T; i += 256) { float v = (float)p[i] * scale; rowbuf[i] = v; mx = fmaxf(mx, v); }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = threadIdx.x; i < T; i += 256) { float e = __expf(rowbuf[i] - mx); rowbuf[i] = e; s += e; }
+    float tot = block_sum(s, red + 4);
+    __shared__ float inv;
+    if (threadIdx.x == 0) inv = 1.f / tot;
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) p[i] = (_Float16)(rowbuf[i] * inv);
+}
+
+// ------------------------------------------------------------------------------------------ small helpers
+__global__ void k_concat(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2, _Float16* __restrict__ y, long rows) {
+    const int nchunk = (C1 + C2) / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * nchunk; i += (long)gridDim.x * blockDim.x) {
+        long r = i / nchunk; int ch = (int)(i % nchunk) * 8;
+        *(h8*)(y + r * (C1 + C2) + ch) = ch < C1 ? *(const h8*)(x1 + r * C1 + ch) : *(const h8*)(x2 + r * C2 + ch - C1);
+    }
+}
+// [B,H,W,Cin] -> [B*Ho*Wo, Kpad] im2col for 3x3 convs with tiny Cin (conv_in 8->320, VAE 3->128 / 4->512)
+__global__ void k_im2col_small(const _Float16* __restrict__ x, _Float16* __restrict__ out, int B, int H, int W, int Cin, int Kpad) {
+    const long total = (long)B * H * W * Kpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % Kpad); long m = i / Kpad;
+        _Float16 v = (_Float16)0.f;
+        if (k < 9 * Cin) {
+            int tap = k / Cin, c = k - tap * Cin, ky = tap / 3, kx = tap - ky * 3;
+            int xx = (int)(m % W), yy = (int)((m / W) % H); long b = m / ((long)W * H);
+            int iy = yy + ky - 1, ix = xx + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * H + iy) * W + ix) * Cin + c];
+        }
+        out[i] = v;
+    }
+}
+// y[n] = act(W[n,:] . x + b[n]) -- one wave per output (time-embedding MLP, per-ResBlock time projection)
+__global__ __launch_bounds__(256) void k_gemv(const _Float16* __restrict__ W, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
+                                              const _Float16* __restrict__ add, _Float16* __restrict__ y, int N, int K, int silu_in, int silu_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        h8 w = *(const h8*)(W + (long)n * K + k), v = *(const h8*)(x + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float xv = (float)v[j]; if (silu_in) xv = (float)(_Float16)(xv / (1.f + __expf(-xv))); s += (float)w[j] * xv; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += bias ? (float)bias[n] : 0.f;
+        if (silu_out) s = s / (1.f + __expf(-s));
+        if (add) s = (float)(_Float16)s + (float)add[n];
+        y[n] = (_Float16)s;
+    }
+}
+// sinusoidal timestep embedding, flip_sin_to_cos=True, freq_shift=0 (diffusers Timesteps): [cos | sin], dim 320
+__global__ void k_timestep_embed(float t, int dim, _Float16* __restrict__ out) {
+    const int i = threadIdx.x, half = dim / 2;
+    if (i >= half) return;
+    float freq = __expf(-logf(10000.f) * (float)i / (float)half);
+    out[i] = (_Float16)cosf(t * freq); out[half + i] = (_Float16)sinf(t * freq);
+}
+
+// ------------------------------------------------------------------------------------------ latent pack / unpack
+// mode 0 (xy, generate.py:220-224): image j = frame idx[j];   out[b*F + j][y][x][c] (c<4: x, c>=4: concat_conds), b = 0,1
+// mode 1 (yt, generate.py:267-273 'n c h w -> w c n h'): image j = latent column idx[j], rows = frames sl..sl+nwin, cols = h
+__global__ void k_pack_latents(const _Float16* __restrict__ x, const _Float16* __restrict__ cond, const int* __restrict__ idx, int F,
+                               int mode, int sl, int nwin, int h, int w, _Float16* __restrict__ out) {
+    const int Hh = mode ? nwin : h, Ww = mode ? h : w;
+    const long per = (long)Hh * Ww, total = (long)F * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int j = (int)(i / per); long r = i % per; int yy = (int)(r / Ww), xx = (int)(r % Ww);
+        int n = mode ? sl + yy : idx[j], hy = mode ? xx : yy, wx = mode ? idx[j] : xx;
+        h8 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            long src = (((long)n * 4 + c) * h + hy) * w + wx;
+            v[c] = x[src]; v[4 + c] = cond[src];
+        }
+        *(h8*)(out + ((long)j * per + r) * 8) = v;
+        *(h8*)(out + ((long)(F + j) * per + r) * 8) = v;
+    }
+}
+// eps [2F, Hh, Ww, 4] -> noise[n][c][hy][wx] = (u + g*(c - u)) * scale(frame)   (generate.py:349-350, :273-278)
+__global__ void k_unpack_cfg(const _Float16* __restrict__ eps, const int* __restrict__ idx, int F, int mode, int sl, int nwin, int h, int w,
+                             float guidance, int scale_upto, float scale, _Float16* __restrict__ noise) {
+    const int Hh = mode ? nwin : h, Ww = mode ? h : w;
+    const long per = (long)Hh * Ww, total = (long)F * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int j = (int)(i / per); long r = i % per; int yy = (int)(r / Ww), xx = (int)(r % Ww);
+        int n = mode ? sl + yy : idx[j], hy = mode ? xx : yy, wx = mode ? idx[j] : xx;
+        const _Float16* u = eps + ((long)j * per + r) * 4; const _Float16* c = eps + ((long)(F + j) * per + r) * 4;
+        float sc = (mode && n < scale_upto) ? scale : 1.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float uu = (float)u[k], v = uu + guidance * ((float)c[k] - uu);
+            noise[(((long)n * 4 + k) * h + hy) * w + wx] = (_Float16)(v * sc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ AdaIN + fusion (one block per (n,c) plane)
+// nt <- AdaIN(nt, nxy) ; nxy <- sqrt(alpha)*nt + sqrt(1-alpha)*nxy      (generate.py:281-282)
+__global__ __launch_bounds__(256) void k_adain_fuse(_Float16* __restrict__ nt, _Float16* __restrict__ nxy, int hw, float alpha) {
+    __shared__ float red[16]; __shared__ float st[4];
+    _Float16* a = nt + (long)blockIdx.x * hw; _Float16* b = nxy + (long)blockIdx.x * hw;
+    float sa = 0, sb = 0;
+    for (int i = threadIdx.x; i < hw; i += 256) { sa += (float)a[i]; sb += (float)b[i]; }
+    float ta = block_sum(sa, red); if (threadIdx.x == 0) st[0] = ta / hw;
+    float tb = block_sum(sb, red); if (threadIdx.x == 0) st[1] = tb / hw;
+    __syncthreads();
+    const float ma = st[0], mb = st[1];
+    float qa = 0, qb = 0;
+    for (int i = threadIdx.x; i < hw; i += 256) { float d = (float)a[i] - ma; qa += d * d; d = (float)b[i] - mb; qb += d * d; }
+    ta = block_sum(qa, red); if (threadIdx.x == 0) st[2] = sqrtf(ta / (hw - 1) + 1e-5f);
+    tb = block_sum(qb, red); if (threadIdx.x == 0) st[3] = sqrtf(tb / (hw - 1) + 1e-5f);
+    __syncthreads();
+    const float sda = st[2], sdb = st[3], wa = sqrtf(alpha), wb = sqrtf(1.f - alpha);
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float v = ((float)a[i] - ma) / sda * sdb + mb, o = (float)b[i];
+        _Float16 vh = (_Float16)v;
+        a[i] = vh; b[i] = (_Float16)(wa * (float)vh + wb * o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SDE-DPM-Solver++(2M) update (f32 math)
+// x0 = (x - sigma_t*eps)/alpha_t is stored in m0 (f32); x_next = ca*x + cb*(D) + cc*z with D = m0 (order 1)
+// or D = m0 + r1*(m0 - m1) folded on the host into (cb0, cb1).
+__global__ void k_dpm_step(_Float16* __restrict__ x, const _Float16* __restrict__ eps, float* __restrict__ m0, const float* __restrict__ m1,
+                           const _Float16* __restrict__ z, long n, float sigma_t, float alpha_t, float ca, float cb0, float cb1, float cc) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float xv = (float)x[i], x0 = (xv - sigma_t * (float)eps[i]) / alpha_t;
+        float prev = m1 ? m1[i] : 0.f;
+        m0[i] = x0;
+        float r = ca * xv + cb0 * x0 + cb1 * prev + (z ? cc * (float)z[i] : 0.f);
+        x[i] = (_Float16)r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ image <-> NHWC f16
+// img [B,3,H,W] f32 in [0,1] -> out [B,H,W,8] f16 = 2*img-1 (channels 3..7 zero: K padding for the im2col conv)
+__global__ void k_img_to_nhwc(const float* __restrict__ img, _Float16* __restrict__ out, int B, int HW) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * HW; i += (long)gridDim.x * blockDim.x) {
+        long b = i / HW, p = i % HW; h8 v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < 3 ? (_Float16)(2.f * img[(b * 3 + c) * HW + p] - 1.f) : (_Float16)0.f;
+        *(h8*)(out + i * 8) = v;
+    }
+}
+// y [B,HW,ldc] f16 (first 3 channels) -> img [B,3,H,W] f32 = clamp(y/2+0.5, 0, 1)
+__global__ void k_nhwc_to_img(const _Float16* __restrict__ y, int ldc, float* __restrict__ img, int B, int HW) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * HW; i += (long)gridDim.x * blockDim.x) {
+        long b = i / HW, p = i % HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) img[(b * 3 + c) * HW + p] = fminf(fmaxf((float)(_Float16)((float)y[i * ldc + c] * 0.5f + 0.5f), 0.f), 1.f);
+    }
+}
+// generic NHWC f16 [B,HW,ldc] (first C channels, scaled) <-> NCHW f16 [B,C,HW]
+__global__ void k_nhwc_to_nchw(const _Float16* __restrict__ y, int ldc, _Float16* __restrict__ out, int B, int C, int HW, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * HW; i += (long)gridDim.x * blockDim.x) {
+        long b = i / HW, p = i % HW;
+        for (int c = 0; c < C; ++c) out[(b * C + c) * HW + p] = (_Float16)((float)y[i * ldc + c] * scale);
+    }
+}
+__global__ void k_nchw_to_nhwc(const _Float16* __restrict__ x, _Float16* __restrict__ out, int ldc, int B, int C, int HW, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * HW; i += (long)gridDim.x * blockDim.x) {
+        long b = i / HW, p = i % HW;
+        for (int c = 0; c < ldc; ++c) out[i * ldc + c] = c < C ? (_Float16)((float)x[(b * C + c) * HW + p] * scale) : (_Float16)0.f;
+    }
+}
+// out[T2, T1] = in[T1, T2]^T (row-major f16), batched
+__global__ void k_transpose(const _Float16* __restrict__ in, _Float16* __restrict__ out, int R, int Cc, int ldi, int ldo) {
+    __shared__ _Float16 t[32][33];
+    const long bo = (long)blockIdx.z;
+    int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) if (x < Cc && y0 + j < R) t[j][threadIdx.x] = in[bo * R * ldi + (long)(y0 + j) * ldi + x];
+    __syncthreads();
+    int xo = blockIdx.y * 32 + threadIdx.x;
+    for (int j = threadIdx.y; j < 32; j += 8) { int yo = blockIdx.x * 32 + j; if (xo < R && yo < Cc) out[bo * Cc * ldo + (long)yo * ldo + xo] = t[threadIdx.x][j]; }
+}
+
+extern "C" {
+
+size_t tcl_groupnorm_workspace_bytes(int B, int C) { return (size_t)B * 64 * 2 * 4 + (size_t)B * C * 2 * 4 + 256; }
+int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
+                      int groups, float eps, int silu, void* ws, hipStream_t st) {
+    const int C = C1 + C2;
+    TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C1 % 8 == 0 && C2 % 8 == 0);
+    TCL_CHECK_ARG(C2 == 0 || x2);
+    float* sums = (float*)ws; float* coef = sums + (size_t)B * 64 * 2;
+    if (hipMemsetAsync(sums, 0, (size_t)B * groups * 2 * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    int blocks = cdiv(HW, 64); if (blocks > 1024) blocks = 1024;
+    int rpb = cdiv(HW, blocks); blocks = cdiv(HW, rpb);
+    hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, sums);
+    hipLaunchKernelGGL(k_gn_coef, dim3(cdiv(C, 256), B), dim3(256), 0, st, sums, (const _Float16*)gamma, (const _Float16*)beta, C, groups,
+                       (float)HW * (float)(C / groups), eps, coef);
+    long chunks = (long)HW * (C / 8);
+    hipLaunchKernelGGL(k_gn_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
+                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, coef, (_Float16*)y, HW, silu);
+    TCL_LAUNCH_RET();
+}
+int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st) {
+    TCL_CHECK_ARG(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048);
+    hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
+                       (_Float16*)y, rows, C, eps);
+    TCL_LAUNCH_RET();
+}
+int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st) {
+    TCL_CHECK_ARG(in && out && rows > 0 && D % 8 == 0);
+    hipLaunchKernelGGL(k_geglu, dim3(stream_grid(rows * (D / 8), 256, 2)), dim3(256), 0, st, (const _Float16*)in, (_Float16*)out, rows, D);
+    TCL_LAUNCH_RET();
+}
+int tcl_softmax_rows_f16(void* x, long rows, int T, int ld, float scale, hipStream_t st) {
+    TCL_CHECK_ARG(x && rows > 0 && T > 0 && (size_t)T * 4 <= 150 * 1024);
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_softmax_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)rows), dim3(256), (size_t)T * 4, st, (_Float16*)x, T, ld, scale);
+    TCL_LAUNCH_RET();
+}
+int tcl_concat_channels_f16(const void* x1, int C1, const void* x2, int C2, void* y, long rows, hipStream_t st) {
+    TCL_CHECK_ARG(x1 && x2 && y && C1 % 8 == 0 && C2 % 8 == 0);
+    hipLaunchKernelGGL(k_concat, dim3(stream_grid(rows * ((C1 + C2) / 8), 256, 2)), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, (_Float16*)y, rows);
+    TCL_LAUNCH_RET();
+}
+int tcl_im2col3x3_small_f16(const void* x, void* out, int B, int H, int W, int Cin, int Kpad, hipStream_t st) {
+    TCL_CHECK_ARG(x && out && Kpad >= 9 * Cin && Kpad % 64 == 0);
+    hipLaunchKernelGGL(k_im2col_small, dim3(stream_grid((long)B * H * W * Kpad, 256, 4)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)out, B, H, W, Cin, Kpad);
+    TCL_LAUNCH_RET();
+}
+int tcl_gemv_f16(const void* W, const void* x, const void* bias, const void* add, void* y, int N, int K, int silu_in, int silu_out, hipStream_t st) {
+    TCL_CHECK_ARG(W && x && y && K % 8 == 0);
+    hipLaunchKernelGGL(k_gemv, dim3(cdiv(N, 4)), dim3(256), 0, st, (const _Float16*)W, (const _Float16*)x, (const _Float16*)bias, (const _Float16*)add,
+                       (_Float16*)y, N, K, silu_in, silu_out);
+    TCL_LAUNCH_RET();
+}
+int tcl_timestep_embed_f16(float t, int dim, void* out, hipStream_t st) {
+    TCL_CHECK_ARG(out && dim % 2 == 0 && dim <= 2048);
+    hipLaunchKernelGGL(k_timestep_embed, dim3(1), dim3(1024), 0, st, t, dim, (_Float16*)out);
+    TCL_LAUNCH_RET();
+}
+int tcl_pack_latents_f16(const void* x, const void* cond, const int* idx, int F, int mode, int sl, int nwin, int h, int w, void* out, hipStream_t st) {
+    TCL_CHECK_ARG(x && cond && idx && out && F > 0);
+    long total = (long)F * (mode ? (long)nwin * h : (long)h * w);
+    hipLaunchKernelGGL(k_pack_latents, dim3(stream_grid(total, 256, 1)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)cond, idx, F, mode, sl, nwin, h, w, (_Float16*)out);
+    TCL_LAUNCH_RET();
+}
+int tcl_unpack_cfg_f16(const void* eps, const int* idx, int F, int mode, int sl, int nwin, int h, int w, float guidance, int scale_upto,
+                       float scale, void* noise, hipStream_t st) {
+    TCL_CHECK_ARG(eps && idx && noise && F > 0);
+    long total = (long)F * (mode ? (long)nwin * h : (long)h * w);
+    hipLaunchKernelGGL(k_unpack_cfg, dim3(stream_grid(total, 256, 1)), dim3(256), 0, st, (const _Float16*)eps, idx, F, mode, sl, nwin, h, w, guidance, scale_upto, scale, (_Float16*)noise);
+    TCL_LAUNCH_RET();
+}
+int tcl_adain_fuse_f16(void* noises_t, void* noises, int planes, int hw, float alpha, hipStream_t st) {
+    TCL_CHECK_ARG(noises_t && noises && planes > 0 && hw > 1);
+    hipLaunchKernelGGL(k_adain_fuse, dim3(planes), dim3(256), 0, st, (_Float16*)noises_t, (_Float16*)noises, hw, alpha);
+    TCL_LAUNCH_RET();
+}
+int tcl_dpm_sde_step_f16(void* x, const void* eps, float* m0, const float* m1, const void* z, long n, float sigma_t, float alpha_t, float ca,
+                         float cb0, float cb1, float cc, hipStream_t st) {
+    TCL_CHECK_ARG(x && eps && m0 && n > 0);
+    hipLaunchKernelGGL(k_dpm_step, dim3(stream_grid(n, 256, 2)), dim3(256), 0, st, (_Float16*)x, (const _Float16*)eps, m0, m1, (const _Float16*)z, n, sigma_t, alpha_t, ca, cb0, cb1, cc);
+    TCL_LAUNCH_RET();
+}
+int tcl_img_to_nhwc8_f16(const float* img, void* out, int B, int HW, hipStream_t st) {
+    TCL_CHECK_ARG(img && out);
+    hipLaunchKernelGGL(k_img_to_nhwc, dim3(stream_grid((long)B * HW, 256, 1)), dim3(256), 0, st, img, (_Float16*)out, B, HW);
+    TCL_LAUNCH_RET();
+}
+int tcl_nhwc_to_img_f32(const void* y, int ldc, float* img, int B, int HW, hipStream_t st) {
+    TCL_CHECK_ARG(y && img);
+    hipLaunchKernelGGL(k_nhwc_to_img, dim3(stream_grid((long)B * HW, 256, 1)), dim3(256), 0, st, (const _Float16*)y, ldc, img, B, HW);
+    TCL_LAUNCH_RET();
+}
+int tcl_nhwc_to_nchw_f16(const void* y, int ldc, void* out, int B, int C, int HW, float scale, hipStream_t st) {
+    TCL_CHECK_ARG(y && out);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(stream_grid((long)B * HW, 256, 1)), dim3(256), 0, st, (const _Float16*)y, ldc, (_Float16*)out, B, C, HW, scale);
+    TCL_LAUNCH_RET();
+}
+int tcl_nchw_to_nhwc_f16(const void* x, void* out, int ldc, int B, int C, int HW, float scale, hipStream_t st) {
+    TCL_CHECK_ARG(x && out);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(stream_grid((long)B * HW, 256, 1)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)out, ldc, B, C, HW, scale);
+    TCL_LAUNCH_RET();
+}
+int tcl_transpose_f16(const void* in, void* out, int batch, int R, int Cc, int ldi, int ldo, hipStream_t st) {
+    TCL_CHECK_ARG(in && out);
+    hipLaunchKernelGGL(k_transpose, dim3(cdiv(Cc, 32), cdiv(R, 32), batch), dim3(32, 8), 0, st, (const _Float16*)in, (_Float16*)out, R, Cc, ldi, ldo);
+    TCL_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+// fp16 MFMA GEMM for gfx950 with fused epilogues and an implicit-GEMM 3x3 convolution A-gather.
+//   C[M,N] (f16) = act( A[M,K] (f16) . W[N,K]^T (f16) + bias[N] ) + residual[M,N]      (f32 accumulate)
+// This single kernel family carries every dense contraction of path 1: Linear / conv1x1 (dense A),
+// conv3x3 stride 1|2 with optional nearest-upsampled input (A rows gathered on the fly from NHWC
+// activations, K = 9*Cin tap-major), see SURVEY 8(a) A9.  Replaces the cuBLAS/cuDNN calls that
+// diffusers' UNet2DConditionModel / AutoencoderKL make (reference call sites generate.py:342-347,
+// utils/VidToMe/generate_utils.py:144,161).
+//
+// Tiling: BMxBNx64 block tile, 256 threads = WMxWN waves, each wave (BM/WM)x(BN/WN) out of 32x32x16 f16
+// MFMAs; operands staged global -> VGPR -> LDS (16 B per lane, rows padded to 72 halves = 9 slots so the
+// 16-lane ds_read_b128 groups are conflict-free), double-buffered with one barrier per K-step.
+// Blocks are laid out XCD-aware: XCD x owns M-tiles == x (mod 8) and walks N-tiles fastest so the A tile
+// stays in that XCD's L2 while W (small) is L2-resident everywhere.
+#include "common.h"
+#include "../../include/tclight_hip.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#define BK 64
+#define LDS_STRIDE 72  // halves
+
+struct ConvP {
+    int conv;            // 0: dense A[M][lda]; 1: implicit 3x3
+    int Hin, Win, Cin;   // stored input (before optional upsample)
+    int Hup, Wup;        // logical input size seen by the conv (== Hin,Win unless nearest-upsampled)
+    int Hout, Wout, stride, pad;
+    float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                              const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
+                                              _Float16* __restrict__ C, int M, int N, int K, int lda, int ldc, int ldr, int act,
+                                              ConvP cp, int tiles_m, int tiles_n) {
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* As = (_Float16*)smem;                          // [2][BM][72]
+    _Float16* Bs = As + 2 * BM * LDS_STRIDE;                 // [2][BN][72]
+
+    // XCD-aware tile assignment
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+
+    // per-thread global-load descriptors: chunk c = tid + 256*i -> row c/8, k-chunk c%8 (8 halves)
+    const int kc8 = (tid & 7) * 8;
+    long a_off[A_IT]; int a_oy[A_IT], a_ox[A_IT]; bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + (tid >> 3) + 32 * i;
+        a_ok[i] = m < M;
+        if (!cp.conv) { a_off[i] = (long)m * lda; a_oy[i] = a_ox[i] = 0; }
+        else {
+            int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
+            a_off[i] = (long)b * cp.Hin * cp.Win * cp.Cin; a_oy[i] = oy * cp.stride - cp.pad; a_ox[i] = ox * cp.stride - cp.pad;
+        }
+    }
+    const _Float16* wp[B_IT]; bool w_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) { int n = n0 + (tid >> 3) + 32 * i; w_ok[i] = n < N; wp[i] = W + (long)(w_ok[i] ? n : 0) * K + kc8; }
+
+    uint4 ra[A_IT], rb[B_IT];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        int tap_dy = 0, tap_dx = 0, c0 = k0;
+        if (cp.conv) { int tap = k0 / cp.Cin; c0 = k0 - tap * cp.Cin; tap_dy = tap / 3; tap_dx = tap - tap_dy * 3; }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a_ok[i]) {
+                if (!cp.conv) v = *(const uint4*)(A + a_off[i] + k0 + kc8);
+                else {
+                    int iy = a_oy[i] + tap_dy, ix = a_ox[i] + tap_dx;
+                    if (iy >= 0 && iy < cp.Hup && ix >= 0 && ix < cp.Wup) {
+                        if (cp.Hup != cp.Hin) { iy = min((int)floorf(iy * cp.sy), cp.Hin - 1); ix = min((int)floorf(ix * cp.sx), cp.Win - 1); }
+                        v = *(const uint4*)(A + a_off[i] + ((long)iy * cp.Win + ix) * cp.Cin + c0 + kc8);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[i] = w_ok[i] ? *(const uint4*)(wp[i] + k0) : make_uint4(0, 0, 0, 0);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *(uint4*)(As + (buf * BM + (tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *(uint4*)(Bs + (buf * BN + (tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = rb[i];
+    };
+
+    float16v acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / BK;
+    gload(0); sstore(0);
+    __syncthreads();
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const _Float16* as = As + (cur * BM + wm * (BM / WM) + frow) * LDS_STRIDE + fk;
+        const _Float16* bs = Bs + (cur * BN + wn * (BN / WN) + frow) * LDS_STRIDE + fk;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8 fa[MT], fb[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) fa[a] = *(const half8*)(as + a * 32 * LDS_STRIDE + ks * 16);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = *(const half8*)(bs + b * 32 * LDS_STRIDE + ks * 16);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column n = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32x32 tile
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + wn * (BN / WN) + b * 32 + (lane & 31);
+        if (n >= N) continue;
+        const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int mb = m0 + wm * (BM / WM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m >= M) continue;
+                float v = acc[a][b][r] + bv;
+                if (act == 1) v = v / (1.f + __expf(-v));                       // SiLU
+                if (resid) v += (float)resid[(long)m * ldr + n];
+                C[(long)m * ldc + n] = (_Float16)v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
+                       int K, int lda, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+    const int grid = cdiv(tm, 8) * 8 * tn;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * 2;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, tm, tn);
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
+                    int lda, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+    if (N % 128 == 0 || N > 512) return launch_gemm<128, 128, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, st);
+    return launch_gemm<128, 64, 4, 1>(A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, st);
+}
+
+extern "C" {
+
+int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldc,
+                 int ldr, int act, hipStream_t st) {
+    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && act >= 0 && act <= 1);
+    ConvP cp = {};
+    return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
+                    ldc, ldr, act, cp, st);
+}
+
+int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* resid, void* Y, int B, int Hin, int Win, int Cin,
+                    int Cout, int stride, int pad, int Hup, int Wup, int act, hipStream_t st) {
+    TCL_CHECK_ARG(X && W && Y && B > 0 && Cin % BK == 0 && Cout > 0 && (stride == 1 || stride == 2) && (pad == 0 || pad == 1));
+    ConvP cp;
+    cp.conv = 1; cp.Hin = Hin; cp.Win = Win; cp.Cin = Cin;
+    cp.Hup = Hup > 0 ? Hup : Hin; cp.Wup = Wup > 0 ? Wup : Win;
+    cp.stride = stride; cp.pad = pad;
+    // pad=1: k3 s1|s2 p1 (UNet);  pad=0 & stride 2: the VAE encoder's asymmetric (0,1,0,1) padding
+    cp.Hout = pad ? (cp.Hup + 2 - 3) / stride + 1 : (cp.Hup + 1 - 3) / stride + 1;
+    cp.Wout = pad ? (cp.Wup + 2 - 3) / stride + 1 : (cp.Wup + 1 - 3) / stride + 1;
+    cp.sy = (float)Hin / (float)cp.Hup; cp.sx = (float)Win / (float)cp.Wup;
+    const int M = B * cp.Hout * cp.Wout;
+    return dispatch((const _Float16*)X, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)Y, M, Cout,
+                    9 * Cin, 0, Cout, Cout, act, cp, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""GPU: each path-1 HIP kernel (through the C ABI) against a plain PyTorch fp32 reference of the same op.
+Tolerance: inputs are f16, accumulation f32, outputs rounded to f16 -> rel-L2 <= 2e-3 per op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+H = torch.float16
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd.lib import lib
+    return lib()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (4096, 1280, 640), (300, 960, 320), (77, 64, 768), (129, 2560, 320)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm(L, M, N, K, act):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).to(H)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(H)
+    b = torch.randn(N, device="cuda", generator=g).to(H)
+    R = torch.randn(M, N, device="cuda", generator=g).to(H)
+    C = torch.empty(M, N, device="cuda", dtype=H)
+    L.tcl_gemm_f16(A, W, b, R, C, M, N, K, K, N, N, act, st())
+    ref = A.float() @ W.float().t() + b.float()
+    if act:
+        ref = F.silu(ref)
+    ref = ref + R.float()
+    assert rel(C, ref) < 2e-3
+    C2 = torch.empty(M, N, device="cuda", dtype=H)
+    L.tcl_gemm_f16(A, W, 0, 0, C2, M, N, K, K, N, N, 0, st())
+    assert rel(C2, A.float() @ W.float().t()) < 2e-3
+
+
+@pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,stride,pad,up", [
+    (2, 18, 24, 64, 128, 1, 1, None), (3, 23, 30, 128, 64, 2, 1, None), (2, 12, 15, 64, 64, 1, 1, (23, 30)),
+    (2, 9, 10, 64, 320, 1, 1, (18, 20)), (2, 16, 24, 64, 64, 2, 0, None)])
+def test_conv3x3(L, B, Hh, Ww, Cin, Cout, stride, pad, up):
+    g = torch.Generator(device="cuda").manual_seed(Cin + Cout + Hh)
+    x = torch.randn(B, Cin, Hh, Ww, device="cuda", generator=g).to(H)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (9 * Cin) ** 0.5).to(H)
+    b = torch.randn(Cout, device="cuda", generator=g).to(H)
+    xin = x.float()
+    if up:
+        xin = F.interpolate(xin, size=up, mode="nearest")
+    if pad == 0:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=pad)
+    Ho, Wo = ref.shape[-2:]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_t = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y = torch.empty(B, Ho, Wo, Cout, device="cuda", dtype=H)
+    L.tcl_conv3x3_f16(x_nhwc, w_t, b, 0, y, B, Hh, Ww, Cin, Cout, stride, pad, up[0] if up else 0, up[1] if up else 0, 0, st())
+    assert rel(y.permute(0, 3, 1, 2), ref) < 2e-3
+
+
+def ws_bytes(n):
+    return torch.empty(int(n), dtype=torch.uint8, device="cuda")
+
+
+@pytest.mark.parametrize("C1,C2,silu", [(320, 0, 1), (640, 320, 1), (1280, 640, 0), (128, 0, 1)])
+def test_groupnorm(L, C1, C2, silu):
+    g = torch.Generator(device="cuda").manual_seed(C1)
+    B, HW = 3, 23 * 30
+    x1 = (torch.randn(B, HW, C1, device="cuda", generator=g) * 2 + 0.5).to(H)
+    x2 = torch.randn(B, HW, C2, device="cuda", generator=g).to(H) if C2 else None
+    C = C1 + C2
+    ga, be = torch.randn(C, device="cuda", generator=g).to(H), torch.randn(C, device="cuda", generator=g).to(H)
+    y = torch.empty(B, HW, C, device="cuda", dtype=H)
+    ws = ws_bytes(L.tcl_groupnorm_workspace_bytes(B, C))
+    L.tcl_groupnorm_f16(x1, C1, x2 if C2 else 0, C2, ga, be, y, B, HW, 32, 1e-5, silu, ws, st())
+    x = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, ga.float(), be.float(), 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    assert rel(y, ref) < 2e-3
+
+
+def test_layernorm_geglu_softmax_gemv(L):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for C in (320, 640, 1280):
+        x = (torch.randn(999, C, device="cuda", generator=g) * 3).to(H)
+        ga, be = torch.randn(C, device="cuda", generator=g).to(H), torch.randn(C, device="cuda", generator=g).to(H)
+        y = torch.empty_like(x)
+        L.tcl_layernorm_f16(x, ga, be, y, 999, C, 1e-5, st())
+        assert rel(y, F.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5)) < 2e-3
+    x = torch.randn(500, 2560, device="cuda", generator=g).to(H)
+    y = torch.empty(500, 1280, device="cuda", dtype=H)
+    L.tcl_geglu_f16(x, y, 500, 1280, st())
+    assert rel(y, x[:, :1280].float() * F.gelu(x[:, 1280:].float())) < 2e-3
+    s = (torch.randn(77, 1000, device="cuda", generator=g) * 4).to(H)
+    ref = torch.softmax(s.float() * 0.3, -1)
+    L.tcl_softmax_rows_f16(s, 77, 1000, 1000, 0.3, st())
+    assert rel(s, ref) < 2e-3
+    W = (torch.randn(1280, 320, device="cuda", generator=g) / 18).to(H)
+    v, b, a = (torch.randn(n, device="cuda", generator=g).to(H) for n in (320, 1280, 1280))
+    o = torch.empty(1280, device="cuda", dtype=H)
+    L.tcl_gemv_f16(W, v, b, a, o, 1280, 320, 1, 0, st())
+    assert rel(o, (W.float() @ F.silu(v.float()).to(H).float() + b.float()).to(H).float() + a.float()) < 2e-3
+    te = torch.empty(320, device="cuda", dtype=H)
+    L.tcl_timestep_embed_f16(801.0, 320, te, st())
+    fr = torch.exp(-torch.log(torch.tensor(10000.0)) * torch.arange(160) / 160)
+    ref = torch.cat([torch.cos(801.0 * fr), torch.sin(801.0 * fr)])
+    assert (te.cpu().float() - ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("d,B,Tq,Tk,kv_div", [(40, 2, 300, 300, 1), (40, 2, 1000, 777, 1), (80, 4, 260, 154, 2), (160, 2, 180, 180, 1),
+                                             (80, 2, 129, 64, 1), (40, 2, 64, 2113, 1)])
+def test_attention(L, d, B, Tq, Tk, kv_div):
+    Hh = 8
+    C = Hh * d
+    g = torch.Generator(device="cuda").manual_seed(d + Tq)
+    q = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    k = torch.randn(B // kv_div, Tk, C, device="cuda", generator=g).to(H)
+    v = torch.randn(B // kv_div, Tk, C, device="cuda", generator=g).to(H)
+    o = torch.zeros(B, Tq, C, device="cuda", dtype=H)
+    ws = ws_bytes(L.tcl_attention_workspace_bytes(B, B // kv_div, Hh, Tq, Tk, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 1, ws, st())
+    qq = q.float().view(B, Tq, Hh, d).transpose(1, 2)
+    kk = k.float().view(-1, Tk, Hh, d).transpose(1, 2).repeat_interleave(kv_div, 0)
+    vv = v.float().view(-1, Tk, Hh, d).transpose(1, 2).repeat_interleave(kv_div, 0)
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, Tq, C)
+    assert rel(o, ref) < 3e-3
+    # strided fused-QKV input + reuse of packed K/V
+    qkv = torch.cat([q, k.repeat_interleave(kv_div, 0)[:, :Tq] if Tk >= Tq else q, q], -1) if False else None
+    o2 = torch.zeros_like(o)
+    L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o2, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 0, ws, st())
+    assert torch.equal(o, o2)
+
+
+def test_pack_unpack_adain(L):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N, h, w = 7, 10, 12
+    x = torch.randn(N, 4, h, w, device="cuda", generator=g).to(H)
+    c = torch.randn(N, 4, h, w, device="cuda", generator=g).to(H)
+    idx = torch.tensor([5, 1, 2], dtype=torch.int32, device="cuda")
+    out = torch.empty(6, h, w, 8, device="cuda", dtype=H)
+    L.tcl_pack_latents_f16(x, c, idx, 3, 0, 0, 0, h, w, out, st())
+    ref = torch.cat([x[idx.long()], c[idx.long()]], 1).permute(0, 2, 3, 1)
+    assert torch.equal(out[:3], ref) and torch.equal(out[3:], ref)
+    cols = torch.tensor([11, 0, 4, 7], dtype=torch.int32, device="cuda")
+    sl, nwin = 2, 5
+    out = torch.empty(8, nwin, h, 8, device="cuda", dtype=H)
+    L.tcl_pack_latents_f16(x, c, cols, 4, 1, sl, nwin, h, w, out, st())
+    xt = torch.cat([x, c], 1)[sl:sl + nwin][:, :, :, cols.long()].permute(3, 1, 0, 2)   # 'n c h w -> w c n h'
+    assert torch.equal(out[:4], xt.permute(0, 2, 3, 1))
+    eps = torch.randn(8, nwin, h, 4, device="cuda", generator=g).to(H)
+    noise = torch.zeros(N, 4, h, w, device="cuda", dtype=H)
+    L.tcl_unpack_cfg_f16(eps, cols, 4, 1, sl, nwin, h, w, 2.0, sl + 2, 0.5 ** 0.5, noise, st())
+    e = eps.float().permute(0, 3, 1, 2)                                                    # [2F, c, n, h]
+    pred = e[:4] + 2.0 * (e[4:] - e[:4])                                                   # w c n h
+    refn = torch.zeros(N, 4, h, w, device="cuda")
+    refn[sl:sl + nwin][:, :, :, cols.long()] = pred.permute(2, 1, 3, 0)
+    refn[sl:sl + 2] *= 0.5 ** 0.5
+    assert (noise.float() - refn).abs().max() < 4e-3
+    a, b = torch.randn(N, 4, h, w, device="cuda", generator=g).to(H), (torch.randn(N, 4, h, w, device="cuda", generator=g) * 2 + 1).to(H)
+    a0, b0 = a.float(), b.float()
+    L.tcl_adain_fuse_f16(a, b, N * 4, h * w, 0.01, st())
+    def ms(t):
+        return t.flatten(2).mean(2)[..., None, None], (t.flatten(2).var(2) + 1e-5).sqrt()[..., None, None]
+    ma, sa = ms(a0); mb, sb = ms(b0)
+    ra = (a0 - ma) / sa * sb + mb
+    assert rel(a, ra) < 2e-3 and rel(b, 0.1 * ra + 0.99 ** 0.5 * b0) < 2e-3

@@ -119,10 +119,30 @@ int tcl_transpose_f16(const void* in, void* out, int batch, int R, int Cc, int l
 /* softmax(Q K^T * scale) V per head, flash style (torch SDPA / xformers via AttnProcessor2_0: attn1 on the VidToMe-merged
  * tokens, patch.py:170-176, and attn2 text cross-attention).  q/k/v/o point at head 0 of batch 0 with heads interleaved
  * in channels (head hh = channels [hh*d, (hh+1)*d)); ld* row strides and *bs batch strides in halves; d in {40, 80, 160}.
- * K/V batch = b / kv_div.  pack_kv = 0 reuses the K/V panels a previous call left in ws (text K/V are constant per run). */
-size_t tcl_attention_workspace_bytes(int Bq, int Bkv, int H, int Tq, int Tk, int d);
+ * K/V batch = b / kv_div.  pack_kv = 0 reuses the K/V panels a previous call left in ws_kv (text K/V are constant per run). */
+size_t tcl_attention_q_bytes(int B, int H, int Tq, int d);
+size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d);
 int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
-                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws, hipStream_t st);
+                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv,
+                      hipStream_t st);
+
+/* ---- VidToMe token merging (utils/VidToMe/vidtome/merge.py, patch.py:14-91); int32 maps live on the device ---- */
+/* metric / metric.norm(dim=-1) with f16 rounding of the norm and the quotient (merge.py:84, :386). */
+int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t st);
+/* bipartite soft matching with align_batch (merge.py:84-117 randframe, :389-421 2s): cosine scores of src rows a_pos[na]
+ * vs dst rows b_pos[nb] of metric [Bt,T,C] (normalised), batch entries concatenated along dst, greedy row max, stable
+ * descending order; the r best src rows are merged.  The score matrix is never materialised.
+ * Outputs: mrg[na-r+nb] = input position feeding each merged slot ([unmerged src | dst], mode "replace");
+ *          unm[position] = merged slot each input position is restored from (merge.py:135-155). */
+size_t tcl_tome_match_workspace_bytes(int na);
+int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                       int* mrg, int* unm, void* ws, hipStream_t st);
+/* out[i] = outer[off + inner[i]] (inner NULL = identity): composition of unmerge maps (func_warper, vidtome/utils.py:42-48). */
+int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st);
+/* out[b][p] = map[p] >= 0 ? s1[b][map[p]] : s2[b][~map[p]]  (merge in "replace" mode; map NULL = copy). */
+int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, const int* map, void* out, long bso, int Bt, int n, int C, hipStream_t st);
+/* h[b][i] += y[b][map[i]]  (unmerge + residual add, patch.py:178-179). */
+int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -204,22 +204,23 @@ static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 extern "C" {
 
 // panel sizes: Tqp = ceil128(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d)
-size_t tcl_attention_workspace_bytes(int Bq, int Bkv, int H, int Tq, int Tk, int d) {
-    size_t q = (size_t)Bq * H * rup(Tq, 128) * rup(d, 16), k = (size_t)Bkv * H * rup(Tk, 64) * rup(d, 16), v = (size_t)Bkv * H * rup(d, 32) * rup(Tk, 64);
-    return (q + k + v) * 2 + 1024;
+size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 128) * rup(d, 16) * 2 + 256; }
+size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
+    return ((size_t)Bkv * H * rup(Tk, 64) * rup(d, 16) + (size_t)Bkv * H * rup(d, 32) * rup(Tk, 64)) * 2 + 256;
 }
 
 // softmax(Q K^T * scale) V per head.  q/k/v point at head 0 of batch 0; row strides ld* and batch strides *bs in halves.
 // K/V batch index = b / kv_div (kv_div = F for the text cross-attention whose context repeats per frame, else 1).
-// pack_kv = 0 reuses the K/V panels already in ws (same Bkv, H, Tk, d as the call that packed them).
+// pack_kv = 0 reuses the K/V panels already in ws_kv (same Bkv, H, Tk, d as the call that packed them).
 int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
-                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws, hipStream_t st) {
-    TCL_CHECK_ARG(q && o && ws && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
+                      long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv,
+                      hipStream_t st) {
+    TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
     TCL_CHECK_ARG(d == 40 || d == 80 || d == 160);
     TCL_CHECK_ARG(!pack_kv || (k && v));
     const int Tqp = rup(Tq, 128), Tkp = rup(Tk, 64), DP = rup(d, 16), DPV = rup(d, 32), Bkv = B / kv_div;
-    _Float16* Qp = (_Float16*)ws;
-    _Float16* Kp = Qp + (size_t)B * H * Tqp * DP;
+    _Float16* Qp = (_Float16*)ws_q;
+    _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (size_t)Bkv * H * Tkp * DP;
     long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (DP / 8);
     hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,

@@ -1,0 +1,229 @@
+// VidToMe token merging on gfx950 (utils/VidToMe/vidtome/merge.py:20-159 randframe, :343-463 2s; patch.py:14-91).
+// The reference materialises scores [2, n_src, n_dst] in f16, cats the batch along dst, takes row max / argsort.
+// Here: cosine-normalise rows (f16 semantics), one MFMA kernel computes score tiles and reduces them on the fly to a
+// per-src 64-bit key (sortable f16 score << 32 | ~concat_dst_index) with in-lane max + atomicMax -- the score matrix
+// never exists -- then a stable descending radix sort (hipCUB) of the 16-bit scores gives the edge order.  Merging in
+// "replace" mode and unmerging are pure row gathers driven by int32 maps built on the device; the global-token bank
+// stays on the device (the reference round-trips it through the CPU for every block and chunk, patch.py:65-82).
+// Tie rule (the reference's is unspecified on GPU): highest score, then lowest concatenated dst index; equal scores
+// keep ascending src order.
+#include "common.h"
+#include "../../include/tclight_hip.h"
+#include <hipcub/hipcub.hpp>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+#define MS 72   // LDS row stride (halves) for a 64-wide K step
+
+__global__ __launch_bounds__(256) void k_tome_normalize(const _Float16* __restrict__ x, _Float16* __restrict__ y, long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C / 8;
+    half8 v[4]; float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < nchunk) { v[k] = *(const half8*)(x + row * C + (lane + 64 * k) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (float)v[k][j] * (float)v[k][j]; }
+    const float nrm = (float)(_Float16)sqrtf(wave_sum(q));   // norm rounded to f16, then an f16 division
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (lane + 64 * k < nchunk) { half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[k][j] / nrm);
+            *(half8*)(y + row * C + (lane + 64 * k) * 8) = o; }
+}
+
+__device__ __forceinline__ unsigned sortable16(_Float16 h) {
+    unsigned short b = __builtin_bit_cast(unsigned short, h);
+    return (b & 0x8000u) ? (unsigned)(unsigned short)~b : (unsigned)(b | 0x8000u);
+}
+
+// keys[src] = max over (batch, dst) of (sortable(f16(score)) << 32 | ~(batch*nb + dst))
+__global__ __launch_bounds__(256) void k_tome_match(const _Float16* __restrict__ metric, long bstride, int C, const int* __restrict__ a_pos,
+                                                    int na, const int* __restrict__ b_pos, int nb, int tiles_src,
+                                                    unsigned long long* __restrict__ keys) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Ds = (_Float16*)smem;            // dst tile  [2][128][MS]  (MFMA A operand: rows of S^T)
+    _Float16* Ss = Ds + 2 * 128 * MS;          // src tile  [2][128][MS]  (MFMA B operand: cols of S^T)
+    const int tsrc = blockIdx.x % tiles_src, tdst = blockIdx.x / tiles_src, bb = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const _Float16* base = metric + (long)bb * bstride;
+    const int kc8 = (tid & 7) * 8;
+    const _Float16* dp[4]; const _Float16* sp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = (tid >> 3) + 32 * i, dj = tdst * 128 + r, si = tsrc * 128 + r;
+        dp[i] = dj < nb ? base + (long)b_pos[dj] * C + kc8 : nullptr;
+        sp[i] = si < na ? base + (long)a_pos[si] * C + kc8 : nullptr;
+    }
+    uint4 rd[4], rs[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rd[i] = dp[i] ? *(const uint4*)(dp[i] + kt * 64) : make_uint4(0, 0, 0, 0);
+            rs[i] = sp[i] ? *(const uint4*)(sp[i] + kt * 64) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint4*)(Ds + (buf * 128 + (tid >> 3) + 32 * i) * MS + kc8) = rd[i];
+            *(uint4*)(Ss + (buf * 128 + (tid >> 3) + 32 * i) * MS + kc8) = rs[i];
+        }
+    };
+    float16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nk = C / 64, frow = lane & 31, fk = (lane >> 5) * 8;
+    gload(0); sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const _Float16* ds = Ds + (cur * 128 + wm * 64 + frow) * MS + fk;
+        const _Float16* ss = Ss + (cur * 128 + wn * 64 + frow) * MS + fk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *(const half8*)(ds + a * 32 * MS + ks * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[b] = *(const half8*)(ss + b * 32 * MS + ks * 16);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    // lane owns src column (lane&31) of each of its 2 column tiles; rows = dst
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int si = tsrc * 128 + wn * 64 + b * 32 + (lane & 31);
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int dj = tdst * 128 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (dj < nb) {
+                    unsigned long long key = ((unsigned long long)sortable16((_Float16)acc[a][b][r]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(bb * nb + dj));
+                    best = key > best ? key : best;
+                }
+            }
+        unsigned long long other = __shfl_xor(best, 32, 64);
+        best = other > best ? other : best;
+        if ((lane >> 5) == 0 && si < na) atomicMax(keys + si, best);
+    }
+}
+
+// after the sort: order[k] = src local index of rank k (descending score).  Build the maps of SURVEY 8(a) A12/A13:
+//  mrg[p]  (p in [0, na-r+nb))  = input position feeding merged slot p          (merge, mode "replace")
+//  unm[pos] (pos in input seq)  = merged slot that input position pos is restored from (unmerge)
+__global__ void k_tome_build_maps(const int* __restrict__ order, const unsigned long long* __restrict__ keys, int na, int nb, int r,
+                                  const int* __restrict__ a_pos, const int* __restrict__ b_pos, int* __restrict__ mrg, int* __restrict__ unm) {
+    const int nun = na - r;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
+        if (i < na) {
+            int s = order[i], pos = a_pos[s];
+            if (i >= r) { mrg[i - r] = pos; unm[pos] = i - r; }
+            else { unsigned cidx = 0xFFFFFFFFu - (unsigned)(keys[s] & 0xFFFFFFFFull); unm[pos] = nun + (int)(cidx % (unsigned)nb); }
+        } else {
+            int j = i - na, pos = b_pos[j];
+            mrg[nun + j] = pos; unm[pos] = nun + j;
+        }
+    }
+}
+__global__ void k_keys_to_sort(const unsigned long long* __restrict__ keys, unsigned* __restrict__ k16, int* __restrict__ iota, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { k16[i] = (unsigned)(keys[i] >> 32); iota[i] = i; }
+}
+// out[i] = outer[off + inner[i]]  (inner NULL = identity)
+__global__ void k_index_compose(const int* __restrict__ outer, const int* __restrict__ inner, int off, int n, int* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = outer[off + (inner ? inner[i] : i)];
+}
+// out[bb][p] = map[p] >= 0 ? s1[bb][map[p]] : s2[bb][~map[p]]   (map NULL = identity copy of s1)
+__global__ void k_gather_rows(const _Float16* __restrict__ s1, long bs1, const _Float16* __restrict__ s2, long bs2, const int* __restrict__ map,
+                              _Float16* __restrict__ out, long bso, int n, int C) {
+    const int nchunk = C / 8, bb = blockIdx.y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * nchunk; i += (long)gridDim.x * blockDim.x) {
+        int p = (int)(i / nchunk), c8 = (int)(i % nchunk) * 8, m = map ? map[p] : p;
+        const _Float16* src = m >= 0 ? s1 + bb * bs1 + (long)m * C : s2 + bb * bs2 + (long)(~m) * C;
+        *(half8*)(out + bb * bso + (long)p * C + c8) = *(const half8*)(src + c8);
+    }
+}
+// h[bb][i] += y[bb][map[i]]   (unmerge + residual)
+__global__ void k_gather_add_rows(_Float16* __restrict__ h, long bsh, const _Float16* __restrict__ y, long bsy, const int* __restrict__ map, int n, int C) {
+    const int nchunk = C / 8, bb = blockIdx.y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * nchunk; i += (long)gridDim.x * blockDim.x) {
+        int p = (int)(i / nchunk), c8 = (int)(i % nchunk) * 8;
+        half8 a = *(half8*)(h + bb * bsh + (long)p * C + c8), b = *(const half8*)(y + bb * bsy + (long)(map ? map[p] : p) * C + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (_Float16)((float)a[j] + (float)b[j]);
+        *(half8*)(h + bb * bsh + (long)p * C + c8) = a;
+    }
+}
+
+extern "C" {
+
+int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t st) {
+    TCL_CHECK_ARG(x && y && rows > 0 && C % 8 == 0 && C <= 2048);
+    hipLaunchKernelGGL(k_tome_normalize, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
+    TCL_LAUNCH_RET();
+}
+
+size_t tcl_tome_match_workspace_bytes(int na) {
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, na, 0, 16);
+    return ((size_t)na * 8 + 255) / 256 * 256 + 4 * (((size_t)na * 4 + 255) / 256 * 256) + tmp + 1024;
+}
+
+// bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
+// dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
+// Outputs: mrg int32 [na - r + nb], unm int32 [T'] (indexed by input position; every a_pos/b_pos entry is written).
+int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                       int* mrg, int* unm, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && C % 64 == 0);
+    char* p = (char*)ws;
+    auto take = [&](size_t b) { char* q = p; p += (b + 255) / 256 * 256; return q; };
+    unsigned long long* keys = (unsigned long long*)take((size_t)na * 8);
+    unsigned* k_in = (unsigned*)take((size_t)na * 4); unsigned* k_out = (unsigned*)take((size_t)na * 4);
+    int* v_in = (int*)take((size_t)na * 4); int* order = (int*)take((size_t)na * 4);
+    if (hipMemsetAsync(keys, 0, (size_t)na * 8, st) != hipSuccess) return TCL_ELAUNCH;
+    const int ts = cdiv(na, 128), td = cdiv(nb, 128);
+    const size_t lds = (size_t)4 * 128 * MS * 2;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    hipLaunchKernelGGL(k_tome_match, dim3(ts * td, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, keys);
+    hipLaunchKernelGGL(k_keys_to_sort, dim3(cdiv(na, 256)), dim3(256), 0, st, keys, k_in, v_in, na);
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, k_in, k_out, v_in, order, na, 0, 16, st);
+    if (hipcub::DeviceRadixSort::SortPairsDescending(p, tmp, k_in, k_out, v_in, order, na, 0, 16, st) != hipSuccess) return TCL_ELAUNCH;
+    hipLaunchKernelGGL(k_tome_build_maps, dim3(cdiv(na + nb, 256)), dim3(256), 0, st, order, keys, na, nb, r, a_pos, b_pos, mrg, unm);
+    TCL_LAUNCH_RET();
+}
+int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st) {
+    TCL_CHECK_ARG(outer && out && n > 0);
+    hipLaunchKernelGGL(k_index_compose, dim3(cdiv(n, 256)), dim3(256), 0, st, outer, inner, off, n, out);
+    TCL_LAUNCH_RET();
+}
+int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, const int* map, void* out, long bso, int Bt, int n, int C, hipStream_t st) {
+    TCL_CHECK_ARG(s1 && out && Bt > 0 && n > 0 && C % 8 == 0);
+    int g = stream_grid((long)n * (C / 8), 256, 2); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_gather_rows, dim3(g, Bt), dim3(256), 0, st, (const _Float16*)s1, bs1, (const _Float16*)s2, bs2, map, (_Float16*)out, bso, n, C);
+    TCL_LAUNCH_RET();
+}
+int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st) {
+    TCL_CHECK_ARG(h && y && Bt > 0 && n > 0 && C % 8 == 0);
+    int g = stream_grid((long)n * (C / 8), 256, 2); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_gather_add_rows, dim3(g, Bt), dim3(256), 0, st, (_Float16*)h, bsh, (const _Float16*)y, bsy, map, n, C);
+    TCL_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+"""IC-Light / SD-1.5 UNet forward on the HIP C ABI, with VidToMe token merging in every transformer block.
+
+Host-side mirror of what the reference assembles from diffusers + monkey-patching:
+  UNet2DConditionModel.forward (diffusers 0.32.1; call site generate.py:342-347), the 8-channel conv_in and the
+  concat_conds hook (utils/model_utils.py:21-40), ToMeBlock.forward (utils/VidToMe/vidtome/patch.py:124-201).
+Activations are NHWC f16 [B, H*W, C]; every op below is one C-ABI call (tc_light_amd/csrc/*.hip).  Python only
+sequences launches and owns buffers; there is no torch arithmetic on the data path.
+"""
+import math
+
+import torch
+
+from .lib import lib, stream
+from . import sd15
+from .vidtome import VidToMe
+
+H16 = torch.float16
+
+
+def _dev(t, dev):
+    return t.to(device=dev, dtype=H16).contiguous()
+
+
+def _conv_w(w, dev):          # [Cout,Cin,3,3] -> [Cout, 9*Cin] tap-major
+    return _dev(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), dev)
+
+
+class Ops:
+    """Thin typed wrappers around the C ABI (allocation via torch's caching allocator, launches on the current stream)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.L = lib()
+        self._gn_ws = {}
+
+    def empty(self, *shape, dtype=H16):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def gemm(self, a, w, bias=None, resid=None, act=0, out=None, M=None, lda=None):
+        N, K = w.shape
+        M = M if M is not None else a.numel() // K
+        c = out if out is not None else self.empty(M, N)
+        self.L.tcl_gemm_f16(a, w, bias if bias is not None else 0, resid if resid is not None else 0, c, M, N, K,
+                            lda or K, N, N, act, stream())
+        return c
+
+    def conv3x3(self, x, B, Hh, Ww, cin, w, bias, resid=None, stride=1, pad=1, up=None):
+        cout = w.shape[0]
+        Hu, Wu = up if up else (Hh, Ww)
+        Ho = (Hu + 2 - 3) // stride + 1 if pad else (Hu + 1 - 3) // stride + 1
+        Wo = (Wu + 2 - 3) // stride + 1 if pad else (Wu + 1 - 3) // stride + 1
+        y = self.empty(B * Ho * Wo, cout)
+        self.L.tcl_conv3x3_f16(x, w, bias if bias is not None else 0, resid if resid is not None else 0, y, B, Hh, Ww, cin, cout,
+                               stride, pad, up[0] if up else 0, up[1] if up else 0, 0, stream())
+        return y, Ho, Wo
+
+    def groupnorm(self, x1, c1, gamma, beta, B, HW, eps, silu, x2=None, c2=0, groups=32):
+        key = (B, c1 + c2)
+        ws = self._gn_ws.get(key)
+        if ws is None:
+            ws = self._gn_ws[key] = torch.empty(self.L.tcl_groupnorm_workspace_bytes(B, c1 + c2), dtype=torch.uint8, device=self.dev)
+        y = self.empty(B * HW, c1 + c2)
+        self.L.tcl_groupnorm_f16(x1, c1, x2 if x2 is not None else 0, c2, gamma, beta, y, B, HW, groups, eps, int(silu), ws, stream())
+        return y
+
+    def layernorm(self, x, gamma, beta, rows, C):
+        y = self.empty(rows, C)
+        self.L.tcl_layernorm_f16(x, gamma, beta, y, rows, C, 1e-5, stream())
+        return y
+
+    def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1):
+        o = self.empty(B * Tq, Hh * d)
+        wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
+        if ws_kv is None:
+            ws_kv = torch.empty(self.L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d), dtype=torch.uint8, device=self.dev)
+        self.L.tcl_attention_f16(q, ldq, qbs, k if k is not None else 0, ldk, kbs, v if v is not None else 0, ldv, vbs, o, Hh * d,
+                                 Tq * Hh * d, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, pack_kv, wq, ws_kv, stream())
+        return o
+
+
+class UNetEngine:
+    """unet(sample[2F,4,h',w'], t, encoder_hidden_states=[2F,L,768], cross_attention_kwargs={'concat_conds': ...}).sample
+    is served by `forward_nhwc` (NHWC in/out) so that the pack/unpack kernels can feed it without layout round trips."""
+
+    in_channels = 4   # unet.config.in_channels stays 4 (generate.py:174)
+
+    def __init__(self, state_dict, device, vidtome=None):
+        self.dev = torch.device(device)
+        self.ops = Ops(self.dev)
+        self.L = lib()
+        self.tome = vidtome if vidtome is not None else VidToMe(self.dev)
+        sd = state_dict
+        exp = sd15.unet_param_shapes()
+        missing = [k for k in exp if k not in sd]
+        if missing:
+            raise KeyError(f"UNet state dict lacks {len(missing)} keys, e.g. {missing[:3]}")
+        d = self.dev
+        w = {}
+        ci = sd["conv_in.weight"]
+        wi = torch.zeros(320, 128)
+        wi[:, :9 * ci.shape[1]] = ci.permute(0, 2, 3, 1).reshape(320, -1)
+        w["conv_in"] = (_dev(wi, d), _dev(sd["conv_in.bias"], d), ci.shape[1])
+        w["t1"] = (_dev(sd["time_embedding.linear_1.weight"], d), _dev(sd["time_embedding.linear_1.bias"], d))
+        w["t2"] = (_dev(sd["time_embedding.linear_2.weight"], d), _dev(sd["time_embedding.linear_2.bias"], d))
+        self.res, self.tfm = {}, {}
+        for k in exp:
+            if k.endswith("norm1.weight") and ".resnets." in k:
+                self.res[k[:-len("norm1.weight")]] = None
+            if k.endswith("proj_in.weight"):
+                self.tfm[k[:-len("proj_in.weight")]] = None
+        for p in self.res:
+            r = dict(n1=(_dev(sd[p + "norm1.weight"], d), _dev(sd[p + "norm1.bias"], d)),
+                     c1=_conv_w(sd[p + "conv1.weight"], d), b1=_dev(sd[p + "conv1.bias"], d),
+                     tw=_dev(sd[p + "time_emb_proj.weight"], d), tb=_dev(sd[p + "time_emb_proj.bias"], d),
+                     n2=(_dev(sd[p + "norm2.weight"], d), _dev(sd[p + "norm2.bias"], d)),
+                     c2=_conv_w(sd[p + "conv2.weight"], d), b2=_dev(sd[p + "conv2.bias"], d),
+                     cin=sd[p + "conv1.weight"].shape[1], cout=sd[p + "conv1.weight"].shape[0])
+            if p + "conv_shortcut.weight" in sd:
+                r["sc"] = (_dev(sd[p + "conv_shortcut.weight"].flatten(1), d), _dev(sd[p + "conv_shortcut.bias"], d))
+            self.res[p] = r
+        for p in self.tfm:
+            t = p + "transformer_blocks.0."
+            c = sd[p + "proj_in.weight"].shape[0]
+            self.tfm[p] = dict(
+                c=c, gn=(_dev(sd[p + "norm.weight"], d), _dev(sd[p + "norm.bias"], d)),
+                pin=(_dev(sd[p + "proj_in.weight"].flatten(1), d), _dev(sd[p + "proj_in.bias"], d)),
+                pout=(_dev(sd[p + "proj_out.weight"].flatten(1), d), _dev(sd[p + "proj_out.bias"], d)),
+                ln=[(_dev(sd[t + f"norm{i}.weight"], d), _dev(sd[t + f"norm{i}.bias"], d)) for i in (1, 2, 3)],
+                qkv=_dev(torch.cat([sd[t + "attn1.to_q.weight"], sd[t + "attn1.to_k.weight"], sd[t + "attn1.to_v.weight"]]), d),
+                o1=(_dev(sd[t + "attn1.to_out.0.weight"], d), _dev(sd[t + "attn1.to_out.0.bias"], d)),
+                q2=_dev(sd[t + "attn2.to_q.weight"], d),
+                kv2=_dev(torch.cat([sd[t + "attn2.to_k.weight"], sd[t + "attn2.to_v.weight"]]), d),
+                o2=(_dev(sd[t + "attn2.to_out.0.weight"], d), _dev(sd[t + "attn2.to_out.0.bias"], d)),
+                ff1=(_dev(sd[t + "ff.net.0.proj.weight"], d), _dev(sd[t + "ff.net.0.proj.bias"], d)),
+                ff2=(_dev(sd[t + "ff.net.2.weight"], d), _dev(sd[t + "ff.net.2.bias"], d)),
+                text_kv={})
+        for i in range(3):
+            w[f"down{i}"] = (_conv_w(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"], d), _dev(sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], d))
+            w[f"up{i}"] = (_conv_w(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"], d), _dev(sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], d))
+        w["norm_out"] = (_dev(sd["conv_norm_out.weight"], d), _dev(sd["conv_norm_out.bias"], d))
+        w["conv_out"] = (_conv_w(sd["conv_out.weight"], d), _dev(sd["conv_out.bias"], d))
+        self.w = w
+        self._temb_cache = (None, None)
+        self.flops = 0.0          # algorithmic FLOPs executed (2*MACs), accumulated per forward for the roofline figure
+        self.count_flops = False
+
+    # ------------------------------------------------------------------ time embedding (once per timestep)
+    def _temb(self, t):
+        t = float(t)
+        if self._temb_cache[0] == t:
+            return self._temb_cache[1]
+        o, L = self.ops, self.L
+        e0 = o.empty(320); L.tcl_timestep_embed_f16(t, 320, e0, stream())
+        e1 = o.empty(1280); L.tcl_gemv_f16(self.w["t1"][0], e0, self.w["t1"][1], 0, e1, 1280, 320, 0, 1, stream())
+        emb = o.empty(1280); L.tcl_gemv_f16(self.w["t2"][0], e1, self.w["t2"][1], 0, emb, 1280, 1280, 0, 0, stream())
+        proj = {}
+        for p, r in self.res.items():   # conv1 bias + time_emb_proj(silu(emb)) folded into one per-channel vector
+            v = o.empty(r["cout"])
+            L.tcl_gemv_f16(r["tw"], emb, r["tb"], r["b1"], v, r["cout"], 1280, 1, 0, stream())
+            proj[p] = v
+        self._temb_cache = (t, proj)
+        return proj
+
+    # ------------------------------------------------------------------ blocks
+    def _resblock(self, p, x, B, Hh, Ww, tproj, skip=None, cskip=0):
+        o, r = self.ops, self.res[p]
+        HW = Hh * Ww
+        cx = r["cin"] - cskip
+        hn = o.groupnorm(x, cx, *r["n1"], B, HW, 1e-5, True, x2=skip, c2=cskip)
+        h1, _, _ = o.conv3x3(hn, B, Hh, Ww, r["cin"], r["c1"], tproj[p])
+        hn2 = o.groupnorm(h1, r["cout"], *r["n2"], B, HW, 1e-5, True)
+        if "sc" in r:
+            if skip is not None:
+                xc = o.empty(B * HW, r["cin"])
+                self.L.tcl_concat_channels_f16(x, cx, skip, cskip, xc, B * HW, stream())
+            else:
+                xc = x
+            xs = o.gemm(xc, r["sc"][0], r["sc"][1])
+            self._fl(2.0 * B * HW * r["cin"] * r["cout"])
+        else:
+            xs = x
+        out, _, _ = o.conv3x3(hn2, B, Hh, Ww, r["cout"], r["c2"], r["b2"], resid=xs)
+        self._fl(2.0 * B * HW * 9 * (r["cin"] + r["cout"]) * r["cout"])
+        return out
+
+    def _fl(self, f):
+        if self.count_flops:
+            self.flops += f
+
+    def _text_kv(self, blk, text):
+        key = id(text)
+        hit = blk["text_kv"].get(key)
+        if hit is None:
+            o = self.ops
+            Bt, Lt, _ = text.shape
+            c = blk["c"]
+            kv = o.gemm(text, blk["kv2"])                        # [Bt*L, 2C]: K | V
+            ws = torch.empty(self.L.tcl_attention_kv_bytes(Bt, sd15.HEADS, Lt, c // sd15.HEADS), dtype=torch.uint8, device=self.dev)
+            hit = blk["text_kv"][key] = dict(kv=kv, ws=ws, packed=False, L=Lt, text=text)
+        return hit
+
+    def _transformer(self, p, x, B, F, Hh, Ww, text):
+        o, L, blk = self.ops, self.L, self.tfm[p]
+        C, N, Hd = blk["c"], Hh * Ww, sd15.HEADS
+        d = C // Hd
+        M = B * N
+        hn = o.groupnorm(x, C, *blk["gn"], B, N, 1e-6, False)
+        h = o.gemm(hn, blk["pin"][0], blk["pin"][1])
+        self._fl(2.0 * M * C * C * 2)
+        # ---- attn1 over VidToMe-merged tokens (patch.py:161-179)
+        n1 = o.layernorm(h, *blk["ln"][0], M, C)
+        mg = self.tome.compute_merge(p, n1, F, N, C, Hh * Ww)
+        if mg is None:                                          # downsample > max_downsample: per-frame attention
+            qkv = o.gemm(n1, blk["qkv"])
+            a = o.attention(qkv, 3 * C, N * 3 * C, qkv[:, C:], 3 * C, N * 3 * C, qkv[:, 2 * C:], 3 * C, N * 3 * C, B, Hd, N, N, d)
+            h = o.gemm(a, blk["o1"][0], blk["o1"][1], resid=h)
+            self._fl(2.0 * M * C * C * 4 + 4.0 * B * N * N * C)
+        else:
+            merged, unm, T = mg                                   # merged [2, T, C]
+            qkv = o.gemm(merged, blk["qkv"], M=2 * T)
+            a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
+            y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
+            L.tcl_gather_add_rows_f16(h, F * N * C, y, T * C, unm if unm is not None else 0, 2, F * N, C, stream())
+            self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
+        # ---- attn2: text cross-attention on the full tokens
+        n2 = o.layernorm(h, *blk["ln"][1], M, C)
+        q = o.gemm(n2, blk["q2"])
+        tk = self._text_kv(blk, text)
+        Lt = tk["L"]
+        a = o.attention(q, C, N * C, tk["kv"], 2 * C, Lt * 2 * C, tk["kv"][:, C:], 2 * C, Lt * 2 * C, B, Hd, N, Lt, d,
+                        kv_div=F, ws_kv=tk["ws"], pack_kv=0 if tk["packed"] else 1)
+        tk["packed"] = True
+        h = o.gemm(a, blk["o2"][0], blk["o2"][1], resid=h)
+        self._fl(2.0 * M * C * C * 2 + 4.0 * M * Lt * C)
+        # ---- GEGLU feed-forward
+        n3 = o.layernorm(h, *blk["ln"][2], M, C)
+        f1 = o.gemm(n3, blk["ff1"][0], blk["ff1"][1])
+        f2 = o.empty(M, 4 * C)
+        L.tcl_geglu_f16(f1, f2, M, 4 * C, stream())
+        h = o.gemm(f2, blk["ff2"][0], blk["ff2"][1], resid=h)
+        self._fl(2.0 * M * C * C * 12)
+        return o.gemm(h, blk["pout"][0], blk["pout"][1], resid=x)
+
+    # ------------------------------------------------------------------ forward
+    def forward_nhwc(self, x_in, F, Hh, Ww, t, text):
+        """x_in [2F, Hh, Ww, 8] f16 (latents | concat_conds); text [2, L, 768] f16 (uncond, cond). -> eps [2F, Hh, Ww, 4] f16."""
+        o, L, w = self.ops, self.L, self.w
+        B = 2 * F
+        tproj = self._temb(t)
+        self.tome.begin_forward(F, (Hh, Ww))
+        col = o.empty(B * Hh * Ww, 128)
+        L.tcl_im2col3x3_small_f16(x_in, col, B, Hh, Ww, w["conv_in"][2], 128, stream())
+        h = o.gemm(col, w["conv_in"][0], w["conv_in"][1])
+        self._fl(2.0 * B * Hh * Ww * 72 * 320)
+        sizes = [(Hh, Ww)]
+        skips = [(h, 320)]
+        hh, ww, c = Hh, Ww, 320
+        for i, co in enumerate(sd15.BLOCK_OUT):
+            for j in range(2):
+                h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
+                c = co
+                if i < 3:
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+                skips.append((h, c))
+            if i < 3:
+                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
+                self._fl(2.0 * B * hh2 * ww2 * 9 * c * c)
+                hh, ww = hh2, ww2
+                sizes.append((hh, ww))
+                skips.append((h, c))
+        h = self._resblock("mid_block.resnets.0.", h, B, hh, ww, tproj)
+        h = self._transformer("mid_block.attentions.0.", h, B, F, hh, ww, text)
+        h = self._resblock("mid_block.resnets.1.", h, B, hh, ww, tproj)
+        level = 3
+        for i, co in enumerate(sd15.BLOCK_OUT[::-1]):
+            for j in range(3):
+                sk, cs = skips.pop()
+                h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
+                if i > 0:
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+            if i < 3:
+                level -= 1
+                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[level])   # nearest upsample fused in the gather
+                self._fl(2.0 * B * hh2 * ww2 * 9 * co * co)
+                hh, ww = hh2, ww2
+        hn = o.groupnorm(h, 320, *w["norm_out"], B, hh * ww, 1e-5, True)
+        eps, _, _ = o.conv3x3(hn, B, hh, ww, 320, *w["conv_out"])
+        self._fl(2.0 * B * hh * ww * 9 * 320 * 4)
+        self.tome.end_forward()
+        return eps

@@ -1,0 +1,138 @@
+"""VidToMe token merging, host side (device-resident state, HIP kernels for all arithmetic).
+
+Mirrors utils/VidToMe/vidtome/patch.py: `apply_patch(...)` arguments live in `VidToMe.args`, `update_patch(pipe,
+global_tokens=None)` is `VidToMe.reset_global_tokens()`, and `compute_merge` (patch.py:14-91) runs per patched
+transformer block.  Differences, all deliberate and documented in DESIGN.md:
+  * the global-token bank of each block stays in HBM (the reference copies it to the CPU and back, patch.py:65-82);
+  * the random choices (`randf`, merge.py:56-58; the src/dst coin, patch.py:61) come from an explicit host stream of
+    draws shared by all blocks of one UNet forward -- in the reference every block owns a generator forked from the same
+    state, so they draw identical numbers in lock-step (vidtome/utils.py:18-30, patch.py:215-231);
+  * ties in the greedy matching are broken deterministically (csrc/merge.hip header).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .lib import lib, stream
+
+H16 = torch.float16
+I32 = torch.int32
+
+
+class VidToMe:
+    def __init__(self, device, local_merge_ratio=0.6, merge_global=True, global_merge_ratio=0.5, max_downsample=2, seed=123,
+                 batch_size=2, align_batch=True, target_stride=4, global_rand=0.5, enabled=True):
+        if batch_size != 2 or not align_batch:
+            raise NotImplementedError("TC-Light runs VidToMe with batch_size=2 (uncond, cond) and align_batch=True")
+        self.dev = torch.device(device)
+        self.args = dict(local_merge_ratio=local_merge_ratio, merge_global=merge_global, global_merge_ratio=global_merge_ratio,
+                         max_downsample=max_downsample, seed=seed, batch_size=batch_size, align_batch=align_batch,
+                         target_stride=target_stride, global_rand=global_rand)
+        self.enabled = enabled
+        self.rng = np.random.default_rng(seed)
+        self.banks = {}                 # block name -> [2, Tb, C] f16 (module.global_tokens, patch.py:60-82)
+        self._pos = {}
+        self._ws = None
+        self.draws = None               # optional injected (randf, coin) for the next forwards (parity tests)
+        self.trace = None               # set to a list to record per-block maps (parity tests)
+        self.L = lib()
+
+    # ---- reference surface
+    def reset_global_tokens(self):      # vidtome.update_patch(pipe, global_tokens=None)  (generate_utils.py:235-238)
+        self.banks.clear()
+
+    def begin_forward(self, F, size):
+        """One UNet forward: fix the draws every patched block will see (lock-step generators of the reference)."""
+        self.F, self.size = F, size
+        if self.draws is not None:
+            self.randf, self.coin = self.draws.pop(0)
+        else:
+            ts = min(self.args["target_stride"], F)
+            self.randf = int(self.rng.integers(0, ts)) if F > 1 else -1
+            self.coin = float(self.rng.random())
+
+    def end_forward(self):
+        pass
+
+    # ---- helpers
+    def _positions(self, F, N, randf):
+        key = (F, N, randf)
+        hit = self._pos.get(key)
+        if hit is None:
+            idx = torch.arange(F * N, dtype=I32)
+            dst = (idx // N) % min(self.args["target_stride"], F) == randf     # merge.py:59-60 (unm_pre = 0)
+            hit = self._pos[key] = (idx[~dst].contiguous().to(self.dev), idx[dst].contiguous().to(self.dev))
+        return hit
+
+    def _range(self, lo, hi):
+        key = ("r", lo, hi)
+        hit = self._pos.get(key)
+        if hit is None:
+            hit = self._pos[key] = torch.arange(lo, hi, dtype=I32, device=self.dev)
+        return hit
+
+    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio):
+        """tokens [2, T, C] -> (mrg [na-r+nb], unm [T]) int32 device maps."""
+        L = self.L
+        r = min(na, int(na * ratio))                                            # merge.py:90
+        metric = torch.empty(2 * T, C, dtype=H16, device=self.dev)
+        L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+        need = L.tcl_tome_match_workspace_bytes(na)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        mrg = torch.empty(na - r + nb, dtype=I32, device=self.dev)
+        unm = torch.empty(T, dtype=I32, device=self.dev)
+        L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, self._ws, stream())
+        return mrg, unm, na - r + nb
+
+    # ---- patch.py:14-91
+    def compute_merge(self, name, x, F, N, C, _unused=None):
+        """x: norm1 output [2F, N, C] (== joined [2, F*N, C]).  Returns None when this block is not merged, else
+        (merged [2,T,C], unm int32 [F*N] or None for identity, T)."""
+        a = self.args
+        if not self.enabled:
+            return None
+        downsample = int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N)))   # patch.py:15-17
+        if downsample > a["max_downsample"]:
+            return None
+        L = self.L
+        if F > 1:
+            a_pos, b_pos = self._positions(F, N, self.randf)
+            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, (F - 1) * N, b_pos, N, a["local_merge_ratio"])
+            local = torch.empty(2, TL, C, dtype=H16, device=self.dev)
+            L.tcl_gather_rows_f16(x, F * N * C, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
+        else:
+            mrg1 = unm1 = None
+            local, TL = x, N
+        if not a["merge_global"]:
+            return local, unm1, TL
+        bank = self.banks.get(name)
+        if bank is None:                                                        # patch.py:81-82: the first chunk seeds the bank
+            self.banks[name] = local if F > 1 else local.clone()
+            if self.trace is not None:
+                self.trace.append(dict(name=name, unm=unm1, gather=mrg1, T=TL))
+            return local, unm1, TL
+        Tb = bank.shape[1]
+        if self.coin > a["global_rand"]:                                        # patch.py:61-65: local tokens are src
+            src_len, loff, boff = TL, 0, TL
+        else:                                                                   # patch.py:66-70: bank tokens are src
+            src_len, loff, boff = Tb, Tb, 0
+        T = TL + Tb
+        cat = torch.empty(2, T, C, dtype=H16, device=self.dev)
+        L.tcl_gather_rows_f16(local, TL * C, 0, 0, 0, cat[:, loff:], T * C, 2, TL, C, stream())
+        L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, 2, Tb, C, stream())
+        mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
+                                     a["global_merge_ratio"])
+        merged = torch.empty(2, Tm, C, dtype=H16, device=self.dev)
+        L.tcl_gather_rows_f16(cat, T * C, 0, 0, mrg2, merged, Tm * C, 2, Tm, C, stream())
+        unm = torch.empty(F * N, dtype=I32, device=self.dev)
+        L.tcl_index_compose(unm2, unm1 if unm1 is not None else 0, loff, F * N, unm, stream())    # 2s-unmerge then randframe-unmerge
+        bmap = torch.empty(TL, dtype=I32, device=self.dev)                     # bank <- u(merged_tokens) (patch.py:80)
+        L.tcl_index_compose(mrg2, unm2[loff:], 0, TL, bmap, stream())
+        nb_ = torch.empty(2, TL, C, dtype=H16, device=self.dev)
+        L.tcl_gather_rows_f16(cat, T * C, 0, 0, bmap, nb_, TL * C, 2, TL, C, stream())
+        self.banks[name] = nb_
+        if self.trace is not None:
+            self.trace.append(dict(name=name, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL))
+        return merged, unm, Tm

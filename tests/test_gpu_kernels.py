@@ -126,17 +126,16 @@ def test_attention(L, d, B, Tq, Tk, kv_div):
     k = torch.randn(B // kv_div, Tk, C, device="cuda", generator=g).to(H)
     v = torch.randn(B // kv_div, Tk, C, device="cuda", generator=g).to(H)
     o = torch.zeros(B, Tq, C, device="cuda", dtype=H)
-    ws = ws_bytes(L.tcl_attention_workspace_bytes(B, B // kv_div, Hh, Tq, Tk, d))
-    L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 1, ws, st())
+    wq, wkv = ws_bytes(L.tcl_attention_q_bytes(B, Hh, Tq, d)), ws_bytes(L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 1, wq, wkv, st())
     qq = q.float().view(B, Tq, Hh, d).transpose(1, 2)
     kk = k.float().view(-1, Tk, Hh, d).transpose(1, 2).repeat_interleave(kv_div, 0)
     vv = v.float().view(-1, Tk, Hh, d).transpose(1, 2).repeat_interleave(kv_div, 0)
     ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, Tq, C)
     assert rel(o, ref) < 3e-3
     # strided fused-QKV input + reuse of packed K/V
-    qkv = torch.cat([q, k.repeat_interleave(kv_div, 0)[:, :Tq] if Tk >= Tq else q, q], -1) if False else None
     o2 = torch.zeros_like(o)
-    L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o2, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 0, ws, st())
+    L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o2, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 0, wq, wkv, st())
     assert torch.equal(o, o2)
 
 

@@ -1,0 +1,109 @@
+"""GPU parity of the UNet engine (HIP, f16) against the fp32 CPU oracle on identical seeded weights and inputs.
+
+Stage (i)  -- VidToMe indices injected from the HIP run into the oracle: pure numeric parity of ~700 chained kernels.
+              Tolerance: rel-L2 <= 1e-2 on eps (f16 activations/weights vs f32 oracle; measured ~2-4e-3).
+Stage (ii) -- oracle computes its own matching with the f16-emulating rule: report map agreement and rel-L2.
+The oracle's UNet arithmetic itself is parity-UNPINNED w.r.t. diffusers (see oracle/sd15.py header).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd import sd15
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vidtome import VidToMe
+    sd = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
+    assert sum(v.numel() for v in sd.values()) == 859_520_964 + 320 * 4 * 9      # SD-1.5 UNet + 4 extra conv_in channels
+    tome = VidToMe("cuda", seed=5)
+    eng = UNetEngine(sd, "cuda", tome)
+    return sd, eng, tome
+
+
+def _inputs(F, Hh, Ww, seed):
+    g = np.random.default_rng(seed)
+    x = torch.from_numpy(g.standard_normal((F, 8, Hh, Ww)).astype(np.float32)).half().float()
+    text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32)).half().float()
+    return x, text
+
+
+def _run_hip(eng, x, text_dev, F, Hh, Ww, t):
+    xin = torch.cat([x, x]).permute(0, 2, 3, 1).contiguous().cuda().half()        # cat([x,x]) (generate.py:298), NHWC
+    eps = eng.forward_nhwc(xin, F, Hh, Ww, t, text_dev)
+    torch.cuda.synchronize()
+    return eps.view(2 * F, Hh, Ww, 4).permute(0, 3, 1, 2).float().cpu()
+
+
+def test_unet_two_chunks(setup):
+    from oracle import sd15 as OS
+    from oracle import vidtome as OV
+    sd, eng, tome = setup
+    F, Hh, Ww, t = 2, 16, 24, 801.0
+    text = _inputs(F, Hh, Ww, 0)[1]
+    text_dev = text.cuda().half()
+    tome.reset_global_tokens()
+    tome.trace = []
+    tome.draws = [(1, 0.9), (0, 0.2)]              # chunk 0 seeds the banks; chunk 1: coin 0.2 <= 0.5 -> bank tokens are src
+    xs = [_inputs(F, Hh, Ww, 10 + k)[0] for k in range(2)]
+    hip = [_run_hip(eng, xs[k], text_dev, F, Hh, Ww, t) for k in range(2)]
+    traces = tome.trace
+    tome.trace = None
+    assert len(traces) == 20                         # 10 merging blocks (ds 1, 2) x 2 chunks
+    # ---- stage (i): inject the HIP maps into the oracle
+    banks = {}
+    it = iter(traces)
+
+    def tome_injected(p, n1):
+        B2, N, C = n1.shape
+        if int(np.ceil(np.sqrt((Hh * Ww) // N))) > 2:
+            return n1, (lambda y: y)
+        tr = next(it)
+        assert tr["name"] == p
+        xj = n1.reshape(2, F * N, C)
+        local = xj[:, tr["mrg1"].cpu().long()] if tr.get("mrg1") is not None else (xj[:, tr["gather"].cpu().long()] if tr.get("gather") is not None else xj)
+        unm = tr["unm"].cpu().long() if tr["unm"] is not None else torch.arange(F * N)
+        if "mrg2" not in tr:
+            banks[p] = local.clone()
+            return local, (lambda y: y[:, unm].reshape(B2, N, C))
+        bank = banks[p]
+        TL, Tb = tr["TL"], bank.shape[1]
+        cat = torch.empty(2, TL + Tb, C)
+        cat[:, tr["loff"]:tr["loff"] + TL] = local
+        cat[:, tr["boff"]:tr["boff"] + Tb] = bank
+        merged = cat[:, tr["mrg2"].cpu().long()]
+        return merged, (lambda y: y[:, unm].reshape(B2, N, C))
+    for k in range(2):
+        ref = OS.unet_forward(sd, torch.cat([xs[k], xs[k]]), t, text, tome_injected)
+        r = rel(hip[k], ref)
+        print(f"[unet parity, injected indices] chunk {k}: rel-L2 = {r:.3e}")
+        assert r < 1e-2, r
+        if k == 0:   # banks for chunk 1 in the oracle = unmerged local tokens; with no bank yet that is `local`
+            pass
+    # ---- stage (ii): oracle's own matching (f16-emulating tie rule), chunk 0 only (no bank dependence)
+    agree = []
+
+    def tome_own(p, n1):
+        B2, N, C = n1.shape
+        if int(np.ceil(np.sqrt((Hh * Ww) // N))) > 2:
+            return n1, (lambda y: y)
+        r = OV.compute_merge(n1, F, None, 1, 0.9, emulate_f16=True)
+        tr = next(t0)
+        agree.append((r["unm"] == tr["unm"].cpu().long()).float().mean().item())
+        return r["merged"], r["unmerge"]
+    t0 = iter(traces[:10])
+    ref = OS.unet_forward(sd, torch.cat([xs[0], xs[0]]), t, text, tome_own)
+    r = rel(hip[0], ref)
+    print(f"[unet parity, computed indices] unmerge-map agreement per block: {['%.3f' % a for a in agree]}; rel-L2 = {r:.3e}")
+    # random-weight activations are close to isotropic noise, so many cosine scores sit within one f16 ulp of each other and
+    # the 1e-3-level activation differences flip some matches; the maps still mostly agree and the output stays close.
+    assert min(agree) > 0.6 and r < 1e-1

@@ -66,10 +66,10 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
 /* ===================================================================== path 1: denoising loop (f16, f32 accumulate)
  * Activations are NHWC / token-major [B, H*W, C] f16 on the device.  These replace the library kernels the reference
  * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */
-/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0, lda % 8 == 0.
- * torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL. */
-int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldc,
-                 int ldr, int act, hipStream_t st);
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0; lda, ldw (row strides of A, W
+ * in halves) % 8 == 0.  torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL. */
+int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
+                 int ldc, int ldr, int act, hipStream_t st);
 /* 3x3 Conv2d as implicit GEMM on NHWC: X [B,Hin,Win,Cin], W [Cout, 9*Cin] (tap-major: (ky*3+kx)*Cin + c), Y [B,Hout,Wout,Cout].
  * pad=1: padding 1 (UNet ResnetBlock2D / Downsample2D stride 2); pad=0 with stride 2: the VAE encoder's (0,1,0,1) padding.
  * Hup/Wup > 0: the input is first nearest-upsampled to Hup x Wup (Upsample2D with explicit output size), fused in the gather. */
@@ -115,6 +115,9 @@ int tcl_nhwc_to_img_f32(const void* y, int ldc, float* img, int B, int HW, hipSt
 int tcl_nhwc_to_nchw_f16(const void* y, int ldc, void* out, int B, int C, int HW, float scale, hipStream_t st);
 int tcl_nchw_to_nhwc_f16(const void* x, void* out, int ldc, int B, int C, int HW, float scale, hipStream_t st);
 int tcl_transpose_f16(const void* in, void* out, int batch, int R, int Cc, int ldi, int ldo, hipStream_t st);
+/* 1x1 Conv2d with <= 8 channels (AutoencoderKL quant_conv 8->8 / post_quant_conv 4->4): y[m, :Co] = W[Co,Ci] x[m, :Ci] + b;
+ * columns Co..ldo-1 of y are zeroed. */
+int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, void* y, int ldo, long M, int Ci, int Co, hipStream_t st);
 
 /* softmax(Q K^T * scale) V per head, flash style (torch SDPA / xformers via AttnProcessor2_0: attn1 on the VidToMe-merged
  * tokens, patch.py:170-176, and attn2 text cross-attention).  q/k/v/o point at head 0 of batch 0 with heads interleaved

@@ -303,8 +303,27 @@ __global__ void k_transpose(const _Float16* __restrict__ in, _Float16* __restric
     for (int j = threadIdx.y; j < 32; j += 8) { int yo = blockIdx.x * 32 + j; if (xo < R && yo < Cc) out[bo * Cc * ldo + (long)yo * ldo + xo] = t[threadIdx.x][j]; }
 }
 
+__global__ void k_conv1x1_small(const _Float16* __restrict__ x, int ldi, const _Float16* __restrict__ W, const _Float16* __restrict__ b,
+                                _Float16* __restrict__ y, int ldo, long M, int Ci, int Co) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        float xi[8];
+        for (int i = 0; i < Ci; ++i) xi[i] = (float)x[m * ldi + i];
+        for (int o = 0; o < ldo; ++o) {
+            float a = 0.f;
+            if (o < Co) { a = (float)b[o]; for (int i = 0; i < Ci; ++i) a += (float)W[o * Ci + i] * xi[i]; }
+            y[m * ldo + o] = (_Float16)a;
+        }
+    }
+}
+
 extern "C" {
 
+int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, void* y, int ldo, long M, int Ci, int Co, hipStream_t st) {
+    TCL_CHECK_ARG(x && W && b && y && Ci > 0 && Ci <= 8 && Co > 0 && Co <= ldo && M > 0);
+    hipLaunchKernelGGL(k_conv1x1_small, dim3(stream_grid(M, 256, 1)), dim3(256), 0, st, (const _Float16*)x, ldi, (const _Float16*)W, (const _Float16*)b,
+                       (_Float16*)y, ldo, M, Ci, Co);
+    TCL_LAUNCH_RET();
+}
 size_t tcl_groupnorm_workspace_bytes(int B, int C) { return (size_t)B * 64 * 2 * 4 + (size_t)B * C * 2 * 4 + 256; }
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {

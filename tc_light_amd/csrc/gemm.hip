@@ -31,7 +31,7 @@ struct ConvP {
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                               const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
-                                              _Float16* __restrict__ C, int M, int N, int K, int lda, int ldc, int ldr, int act,
+                                              _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
                                               ConvP cp, int tiles_m, int tiles_n) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
     }
     const _Float16* wp[B_IT]; bool w_ok[B_IT];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) { int n = n0 + (tid >> 3) + 32 * i; w_ok[i] = n < N; wp[i] = W + (long)(w_ok[i] ? n : 0) * K + kc8; }
+    for (int i = 0; i < B_IT; ++i) { int n = n0 + (tid >> 3) + 32 * i; w_ok[i] = n < N; wp[i] = W + (long)(w_ok[i] ? n : 0) * ldw + kc8; }
 
     uint4 ra[A_IT], rb[B_IT];
     auto gload = [&](int kt) {
@@ -151,30 +151,30 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
-                       int K, int lda, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+                       int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const int grid = cdiv(tm, 8) * 8 * tn;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * 2;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, tm, tn);
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
-                    int lda, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    if (N % 128 == 0 || N > 512) return launch_gemm<128, 128, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, st);
-    return launch_gemm<128, 64, 4, 1>(A, W, bias, resid, C, M, N, K, lda, ldc, ldr, act, cp, st);
+                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+    if (N % 128 == 0 || N > 512) return launch_gemm<128, 128, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    return launch_gemm<128, 64, 4, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
 }
 
 extern "C" {
 
-int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldc,
-                 int ldr, int act, hipStream_t st) {
-    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && act >= 0 && act <= 1);
+int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
+                 int ldc, int ldr, int act, hipStream_t st) {
+    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 1);
     ConvP cp = {};
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
-                    ldc, ldr, act, cp, st);
+                    ldw, ldc, ldr, act, cp, st);
 }
 
 int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* resid, void* Y, int B, int Hin, int Win, int Cin,
@@ -190,7 +190,7 @@ int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* 
     cp.sy = (float)Hin / (float)cp.Hup; cp.sx = (float)Win / (float)cp.Wup;
     const int M = B * cp.Hout * cp.Wout;
     return dispatch((const _Float16*)X, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)Y, M, Cout,
-                    9 * Cin, 0, Cout, Cout, act, cp, st);
+                    9 * Cin, 0, 9 * Cin, Cout, Cout, act, cp, st);
 }
 
 }  // extern "C"

@@ -36,12 +36,13 @@ class Ops:
     def empty(self, *shape, dtype=H16):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
-    def gemm(self, a, w, bias=None, resid=None, act=0, out=None, M=None, lda=None):
-        N, K = w.shape
+    def gemm(self, a, w, bias=None, resid=None, act=0, out=None, M=None, lda=None, N=None, K=None, ldw=None, ldc=None):
+        if N is None:
+            N, K = w.shape
         M = M if M is not None else a.numel() // K
         c = out if out is not None else self.empty(M, N)
         self.L.tcl_gemm_f16(a, w, bias if bias is not None else 0, resid if resid is not None else 0, c, M, N, K,
-                            lda or K, N, N, act, stream())
+                            lda or K, ldw or K, ldc or N, N, act, stream())
         return c
 
     def conv3x3(self, x, B, Hh, Ww, cin, w, bias, resid=None, stride=1, pad=1, up=None):

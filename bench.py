@@ -1,0 +1,221 @@
+"""bench.py -- end-to-end relight throughput of the MI355X TC-Light engine on BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full pass of the hot path over the workload: VAE encode -> 20-step multi-axis denoise (xy + yt planes,
+VidToMe) -> VAE decode -> stage 1 (35 epochs) -> stage 2 (70 epochs), i.e. the region the reference times
+(generate.py:578-611) minus optical-flow estimation (precomputed input).  Workload at N=1 = BASELINE.json
+configs[1]: 30 frames 960x720, 20 steps, --multi_axis; N GPUs relight 30*N frames (weak scaling, frames sharded).
+Weights are seeded random tensors of the SD-1.5 / AutoencoderKL architecture, inputs synthetic (no network); all inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16 (spec; 2.49 PF measured)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=30, help="frames per GPU")
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--n_timesteps", type=int, default=20)
+    ap.add_argument("--epochs_exposure", type=int, default=35)
+    ap.add_argument("--epochs", type=int, default=70)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_multi_axis", action="store_true")
+    return ap.parse_args()
+
+
+def synth_inputs(n, H, W, lo, hi, dev, seed=12345):
+    """translated low-pass frames, analytic backward flow + noise, soft mask, track ids."""
+    import synth
+    d = synth.video_clip(n, H, W, seed=seed)
+    inv, k = synth.track_ids(n, H, W, seed=3)
+    return (d["frames"][lo:hi].to(dev), d["past_flows"].to(dev), d["masks"].to(dev), inv.to(device=dev, dtype=torch.int32), k)
+
+
+def cpu_baseline(sd_unet, H, W, n_frames, n_steps, multi_axis, flops_path1, cfg):
+    """The oracle ("port") timed on this host's cores on a bounded sample, extrapolated by algorithmic work:
+    path 1 by FLOP rate of one full-resolution single-frame UNet evaluation; path 2 by measured time per iteration."""
+    from oracle import path2 as O2
+    from oracle import sd15 as OS
+    import synth
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    h, w = H // 8, W // 8
+    g = np.random.default_rng(0)
+    x = torch.from_numpy(g.standard_normal((2, 8, h, w)).astype(np.float32))
+    text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        OS.unet_forward(sd_unet, x, 801.0, text, None)
+    t_unet = time.perf_counter() - t0
+    fl = unet_flops_unmerged(2, h, w, 77)      # same accounting as UNetEngine._fl (B=2, F=1, no merging)
+    cpu_rate = fl / t_unet
+    d = synth.video_clip(3, H, W, seed=1)
+    inv, _ = synth.track_ids(3, H, W, seed=3)
+    bts = [torch.tensor([1, 2])]
+    t0 = time.perf_counter()
+    O2.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, 2)
+    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]            # per 16-frame iteration
+    iters = (cfg["epochs_exposure"] + cfg["epochs"]) * -(-n_frames // cfg["batch_size"])
+    total = flops_path1 / cpu_rate + iters * t_it2
+    return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle UNet forward on 1 frame {W}x{H} (batch 2, {fl / 1e12:.2f} TFLOP in {t_unet:.1f} s = {cpu_rate / 1e12:.3f} TFLOP/s) "
+                       f"+ 1 oracle stage-2 iteration on 2 frames ({t_it2:.1f} s per 16-frame iteration); extrapolated as "
+                       f"path-1 algorithmic FLOPs / CPU rate + {iters} optimiser iterations")
+
+
+def unet_flops_unmerged(B, h, w, L):
+    """Algorithmic FLOPs (2*MACs) of one UNet call without token merging (SURVEY 8(d) formula)."""
+    C = (320, 640, 1280, 1280)
+    sizes = [(h, w)]
+    for _ in range(3):
+        sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
+    fl = 2.0 * B * h * w * 72 * 320
+
+    def res(cin, cout, n):
+        f = 2.0 * B * n * 9 * (cin + cout) * cout
+        return f + (2.0 * B * n * cin * cout if cin != cout else 0)
+
+    def tfm(c, n):
+        return 2.0 * B * n * c * c * (2 + 4 + 2 + 12) + 4.0 * B * n * n * c + 4.0 * B * n * L * c
+    cin = 320
+    for i, c in enumerate(C):
+        n = sizes[i][0] * sizes[i][1]
+        for _ in range(2):
+            fl += res(cin, c, n) + (tfm(c, n) if i < 3 else 0)
+            cin = c
+        if i < 3:
+            fl += 2.0 * B * sizes[i + 1][0] * sizes[i + 1][1] * 9 * c * c
+    n = sizes[3][0] * sizes[3][1]
+    fl += 2 * res(1280, 1280, n) + tfm(1280, n)
+    rev = C[::-1]
+    prev = 1280
+    for i, c in enumerate(rev):
+        n = sizes[3 - i][0] * sizes[3 - i][1]
+        sk = rev[min(i + 1, 3)]
+        for j in range(3):
+            fl += res((prev if j == 0 else c) + (sk if j == 2 else c), c, n) + (tfm(c, n) if i > 0 else 0)
+        prev = c
+        if i < 3:
+            fl += 2.0 * B * sizes[2 - i][0] * sizes[2 - i][1] * 9 * c * c
+    return fl + 2.0 * B * h * w * 9 * 320 * 4
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (tc_light_amd has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if a.gpus != world:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(ge.LIB):
+        ge.build()
+    from tc_light_amd import sd15
+    from tc_light_amd.generate import Generator
+    from tc_light_amd.lib import lib
+    from tc_light_amd.parallel import Dist
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vae import VAEEngine
+    from tc_light_amd.vidtome import VidToMe
+    d = Dist(rank, world)
+    d.barrier()
+
+    n_total = a.frames * world
+    H, W = a.height, a.width
+    cfg = dict(n_timesteps=a.n_timesteps, alpha_t=0.0 if a.no_multi_axis else 0.01, final_factor_t=0.01, epochs_exposure=a.epochs_exposure,
+               epochs=a.epochs, batch_size=16, seed=12345)
+    sd_unet = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
+    sd_vae = sd15.random_state_dict(sd15.vae_param_shapes(), seed=2)
+    unet = UNetEngine(sd_unet, dev, VidToMe(dev, seed=12345))
+    vae = VAEEngine(sd_vae, dev)
+    gen = Generator(unet, vae, cfg, dist=d)
+    lo, hi = d.range(n_total)
+    frames, flows, masks, inv, K = synth_inputs(n_total, H, W, lo, hi, dev)
+    g = np.random.default_rng(5)
+    conds = torch.from_numpy(g.standard_normal((2, 154, 768)).astype(np.float32)).to(dev).half()     # 2 x 77-token chunks (A4)
+    conds_t = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32)).to(dev).half()
+
+    def one_pass(profile=False):
+        if profile:
+            lib().tcl_flash_profile_begin(40)
+            unet.flops, unet.count_flops = 0.0, True
+        out, info = gen(frames, conds, conds_t, flows, masks, inv, n_total=n_total, k=K)
+        prof = None
+        if profile:
+            ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+            lib().tcl_flash_profile_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+            prof = (ms.value, fl.value, cnt.value)
+            unet.count_flops = False
+        return out, info, prof
+
+    for _ in range(a.warmup):
+        one_pass()
+    d.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = prof = None
+    for s in range(a.steps):
+        out, info, p = one_pass(profile=(s == 0))
+        prof = prof or p
+    d.barrier(); torch.cuda.synchronize()
+    dt = d.max_float(time.perf_counter() - t0, dev)
+    assert torch.isfinite(out).all(), "non-finite output"
+
+    if rank == 0:
+        ms, fl, cnt = prof
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        res = {
+            "metric": "relit frames/sec end-to-end (denoise+2-stage opt)", "value": n_total * a.steps / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{a.frames} frames/GPU {W}x{H}, {a.n_timesteps} denoise steps, "
+                                   f"{'multi_axis (alpha_t=0.01)' if not a.no_multi_axis else 'single axis'}, VidToMe 0.6/0.5, stage-1 "
+                                   f"{a.epochs_exposure} + stage-2 {a.epochs} epochs (BASELINE.json configs[1])",
+                       "frames_total": n_total, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
+                       "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
+            "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
+            "roofline": {"bound": "mfma", "kernel": "k_flash<48,64> (head_dim 40 attention, self + text)", "achieved": ach,
+                         "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": None,
+                         "unet_algorithmic_tflop_per_pass": unet.flops / 1e12},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, a.n_timesteps, not a.no_multi_axis, unet.flops, cfg)
+            except Exception as e:  # the baseline must never sink the measurement
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,9 +99,10 @@ int tcl_timestep_embed_f16(float t, int dim, void* out, hipStream_t st);
  * idx = latent columns, frames sl..sl+nwin. */
 int tcl_pack_latents_f16(const void* x, const void* cond, const int* idx, int F, int mode, int sl, int nwin, int h, int w, void* out, hipStream_t st);
 /* CFG combine uncond + g*(cond - uncond) (generate.py:349-350) scattered back to noises[N,4,h,w]; in mode 1 frames
- * n < scale_upto are multiplied by `scale` (the sqrt(0.5) overlap rule, generate.py:276-278). */
+ * n < scale_upto are multiplied by `scale` (the sqrt(0.5) overlap rule, generate.py:276-278) and only the first nkeep
+ * frames of the window are written (the rest is overwritten by the next window in the reference's sequential order). */
 int tcl_unpack_cfg_f16(const void* eps, const int* idx, int F, int mode, int sl, int nwin, int h, int w, float guidance, int scale_upto,
-                       float scale, void* noise, hipStream_t st);
+                       float scale, int nkeep, void* noise, hipStream_t st);
 /* noises_t <- AdaIN(noises_t, noises); noises <- sqrt(a)*noises_t + sqrt(1-a)*noises  (generate.py:281-282,
  * utils/general_utils.py:137-156).  planes = N*4, hw = h*w. */
 int tcl_adain_fuse_f16(void* noises_t, void* noises, int planes, int hw, float alpha, hipStream_t st);
@@ -146,6 +147,11 @@ int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* o
 int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, const int* map, void* out, long bso, int Bt, int n, int C, hipStream_t st);
 /* h[b][i] += y[b][map[i]]  (unmerge + residual add, patch.py:178-179). */
 int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st);
+
+/* Measurement aid (bench.py roofline leg): bracket every flash-kernel launch (head_dim == dfilter, 0 = all) with HIP events
+ * on its own stream; _end returns the summed kernel time, the algorithmic FLOPs 4*B*H*Tq*Tk*d and the launch count. */
+int tcl_flash_profile_begin(int dfilter);
+int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches);
 
 #ifdef __cplusplus
 }

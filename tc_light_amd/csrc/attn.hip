@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, 
     }
 }
 
+// ---- optional in-library timing of the flash kernel (bench.py roofline leg): HIP events recorded on the launch stream
+#include <vector>
+struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
+static FlashProf g_prof;
+
 template <int DP, int DPV>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
@@ -195,13 +200,35 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)k_flash<DP, DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / 128;
+    const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
     hipLaunchKernelGGL((k_flash<DP, DPV>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    if (prof) { hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 extern "C" {
+
+// Timing of the flash kernel launches (all head dims, or only head_dim == dfilter) with HIP events on their stream.
+int tcl_flash_profile_begin(int dfilter) { g_prof.on = true; g_prof.dfilter = dfilter; g_prof.flops = 0.0; g_prof.launches = 0; g_prof.ev.clear(); return TCL_OK; }
+// -> total kernel ms, algorithmic FLOPs (4*B*H*Tq*Tk*d per launch) and launch count since begin; synchronises the events.
+int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches) {
+    TCL_CHECK_ARG(total_ms && total_flops && launches);
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.ev.size(); i += 2) {
+        float t = 0.f;
+        hipEventSynchronize(g_prof.ev[i + 1]);
+        hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        ms += t;
+        hipEventDestroy(g_prof.ev[i]); hipEventDestroy(g_prof.ev[i + 1]);
+    }
+    *total_ms = ms; *total_flops = g_prof.flops; *launches = g_prof.launches;
+    g_prof.on = false; g_prof.ev.clear();
+    return TCL_OK;
+}
 
 // panel sizes: Tqp = ceil128(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d)
 size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 128) * rup(d, 16) * 2 + 256; }

@@ -207,11 +207,12 @@ __global__ void k_pack_latents(const _Float16* __restrict__ x, const _Float16* _
 }
 // eps [2F, Hh, Ww, 4] -> noise[n][c][hy][wx] = (u + g*(c - u)) * scale(frame)   (generate.py:349-350, :273-278)
 __global__ void k_unpack_cfg(const _Float16* __restrict__ eps, const int* __restrict__ idx, int F, int mode, int sl, int nwin, int h, int w,
-                             float guidance, int scale_upto, float scale, _Float16* __restrict__ noise) {
+                             float guidance, int scale_upto, float scale, int nkeep, _Float16* __restrict__ noise) {
     const int Hh = mode ? nwin : h, Ww = mode ? h : w;
     const long per = (long)Hh * Ww, total = (long)F * per;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int j = (int)(i / per); long r = i % per; int yy = (int)(r / Ww), xx = (int)(r % Ww);
+        if (mode && yy >= nkeep) continue;   // frames the next window overwrites anyway (generate.py:265-278)
         int n = mode ? sl + yy : idx[j], hy = mode ? xx : yy, wx = mode ? idx[j] : xx;
         const _Float16* u = eps + ((long)j * per + r) * 4; const _Float16* c = eps + ((long)(F + j) * per + r) * 4;
         float sc = (mode && n < scale_upto) ? scale : 1.f;
@@ -388,10 +389,10 @@ int tcl_pack_latents_f16(const void* x, const void* cond, const int* idx, int F,
     TCL_LAUNCH_RET();
 }
 int tcl_unpack_cfg_f16(const void* eps, const int* idx, int F, int mode, int sl, int nwin, int h, int w, float guidance, int scale_upto,
-                       float scale, void* noise, hipStream_t st) {
+                       float scale, int nkeep, void* noise, hipStream_t st) {
     TCL_CHECK_ARG(eps && idx && noise && F > 0);
     long total = (long)F * (mode ? (long)nwin * h : (long)h * w);
-    hipLaunchKernelGGL(k_unpack_cfg, dim3(stream_grid(total, 256, 1)), dim3(256), 0, st, (const _Float16*)eps, idx, F, mode, sl, nwin, h, w, guidance, scale_upto, scale, (_Float16*)noise);
+    hipLaunchKernelGGL(k_unpack_cfg, dim3(stream_grid(total, 256, 1)), dim3(256), 0, st, (const _Float16*)eps, idx, F, mode, sl, nwin, h, w, guidance, scale_upto, scale, nkeep, (_Float16*)noise);
     TCL_LAUNCH_RET();
 }
 int tcl_adain_fuse_f16(void* noises_t, void* noises, int planes, int hw, float alpha, hipStream_t st) {

@@ -1,0 +1,172 @@
+"""TC-Light pipeline driver on the MI355X engine -- host-side mirror of generate.py::Generator (reference).
+
+  prepare_data -> _prepare_prompts_and_conditions -> ddim_sample{pred_noise per xy-chunk; temporal_denoise (yt-plane);
+  scheduler.step} -> decode_latents_batch -> exposure_align -> unique_tensor_optimization        (generate.py:560-611)
+
+Python sequences kernel launches and collectives; tensors never leave the device inside the timed region and there is no
+per-iteration host sync (the reference syncs on loss.item() and moves the token bank through the CPU).
+"""
+import math
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .lib import lib, stream
+from . import hostlogic as HL
+from . import post_opt
+from .parallel import Dist, sharded_temporal_pass
+from .scheduler import DPMSolverSDEScheduler
+
+H16 = torch.float16
+I32 = torch.int32
+
+DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections)
+    guidance_scale=2.0, n_timesteps=25, chunk_size=4, chunk_ord="mix-4", local_merge_ratio=0.6, merge_global=True,
+    global_merge_ratio=0.5, global_rand=0.5, align_batch=True, max_downsample=2, noise_mode="same", alpha_t=0.0,
+    final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
+    lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345)
+
+
+class Generator:
+    def __init__(self, unet, vae, config=None, dist=None, scheduler=None):
+        cfg = dict(DEFAULTS)
+        cfg.update(config or {})
+        self.cfg = SimpleNamespace(**cfg)
+        self.unet, self.vae = unet, vae
+        self.dev = unet.dev
+        self.L = lib()
+        self.dist = dist or Dist()
+        self.scheduler = scheduler or DPMSolverSDEScheduler()
+        c = self.cfg
+        # vidtome.apply_patch(...) (generate_utils.py:98-100); max_downsample is NOT forwarded by the reference (default 2)
+        t = self.unet.tome
+        t.args.update(local_merge_ratio=c.local_merge_ratio, merge_global=c.merge_global, global_merge_ratio=c.global_merge_ratio,
+                      global_rand=c.global_rand)
+        self.batch_size = 2
+        self.timing = {}
+
+    # ------------------------------------------------------------------ data
+    def prepare_data(self, frames):
+        """frames: this rank's block [n_local,3,H,W] f32 in [0,1] on the device (generate.py:138-204)."""
+        c = self.cfg
+        self.frames = frames.contiguous()
+        n, _, H, W = frames.shape
+        self.h, self.w = H // 8, W // 8
+        self.n_total = getattr(self, "n_total", None) or n * self.dist.world
+        self.rng_dev = torch.Generator(device=self.dev).manual_seed(int(c.seed))
+        if c.noise_mode.lower() == "same":        # prepare_latents(1, 4, H, W) repeated (generate.py:183-188)
+            z = torch.randn(1, 4, self.h, self.w, generator=self.rng_dev, device=self.dev, dtype=torch.float32)
+            self.init_noise = (z * self.scheduler.init_noise_sigma).to(H16).repeat(n, 1, 1, 1).contiguous()
+        elif c.noise_mode.lower() == "vanilla":
+            z = torch.randn(self.n_total, 4, self.h, self.w, generator=self.rng_dev, device=self.dev, dtype=torch.float32)
+            lo, hi = self.dist.range(self.n_total)
+            self.init_noise = (z[lo:hi] * self.scheduler.init_noise_sigma).to(H16).contiguous()
+        else:
+            raise NotImplementedError(f"Noise mode '{c.noise_mode}' is not supported.")
+
+    # ------------------------------------------------------------------ one UNet evaluation with CFG
+    def _unet_xy(self, x, cc, frames_idx, text, t, noises):
+        """pred_noise on an xy chunk (generate.py:220-224, 288-352): frames_idx = local frame ids."""
+        L, F = self.L, len(frames_idx)
+        idx = torch.tensor(frames_idx, dtype=I32, device=self.dev)
+        xin = torch.empty(2 * F, self.h, self.w, 8, dtype=H16, device=self.dev)
+        L.tcl_pack_latents_f16(x, cc, idx, F, 0, 0, 0, self.h, self.w, xin, stream())
+        eps = self.unet.forward_nhwc(xin, F, self.h, self.w, t, text)
+        L.tcl_unpack_cfg_f16(eps, idx, F, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
+
+    def _unet_yt(self, x_full, cc_full, item, nt_full, text_t, t):
+        """pred_noise on a yt chunk: 'n c h w -> w c n h' over a frame window (generate.py:265-273)."""
+        sl, nwin, cols, scale_upto, nkeep = item
+        L, F = self.L, len(cols)
+        idx = torch.tensor(cols, dtype=I32, device=self.dev)
+        xin = torch.empty(2 * F, nwin, self.h, 8, dtype=H16, device=self.dev)
+        L.tcl_pack_latents_f16(x_full, cc_full, idx, F, 1, sl, nwin, self.h, self.w, xin, stream())
+        eps = self.unet.forward_nhwc(xin, F, nwin, self.h, t, text_t)
+        L.tcl_unpack_cfg_f16(eps, idx, F, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
+                             nkeep, nt_full, stream())
+
+    def _yt_items(self, w_chunks):
+        """(window start, length, columns, scale_upto, nkeep) in the reference's loop order (generate.py:265-278)."""
+        starts, ovl = HL.temporal_windows(self.n_total, self.cfg.win_size_t)
+        items = []
+        for k, sl in enumerate(starts):
+            nwin = min(self.cfg.win_size_t, self.n_total - sl)
+            nkeep = (starts[k + 1] - sl) if k + 1 < len(starts) else nwin
+            up = sl + ovl[k - 1] if k > 0 else 0
+            for ch in w_chunks:
+                items.append((sl, nwin, ch, up, nkeep))
+        return items
+
+    # ------------------------------------------------------------------ hot loop 1
+    @torch.no_grad()
+    def ddim_sample(self, x, conds, conds_t, concat_conds):
+        c, d = self.cfg, self.dist
+        sch = self.scheduler
+        sch.set_timesteps(c.n_timesteps)
+        n_local = x.shape[0]
+        noises = torch.zeros_like(x)
+        noises_t = torch.zeros_like(x)
+        alphas = HL.alpha_schedule(c.alpha_t, c.final_factor_t, len(sch.timesteps))
+        xy_sampler = HL.ChunkSampler(c.seed + 7919 * d.rank, c.chunk_size, c.merge_global, c.chunk_ord)
+        yt_sampler = HL.ChunkSampler(c.seed + 1, c.chunk_size, c.merge_global, c.chunk_ord)
+        cc_full = d.gather_frames(concat_conds, self.n_total) if c.alpha_t > 0 else None
+        lo, hi = d.range(self.n_total)
+        for i, t in enumerate(sch.timesteps.tolist()):
+            for chunk in xy_sampler.get_chunks(n_local):
+                self._unet_xy(x, concat_conds, chunk, conds, t, noises)
+            if c.alpha_t > 0:
+                items = self._yt_items(yt_sampler.get_chunks(self.w))
+                nt = sharded_temporal_pass(d, x, cc_full, self.n_total, items,
+                                           lambda xf, cf, it, out: self._unet_yt(xf, cf, it, out, conds_t, t))
+                noises_t.copy_(nt)
+                self.L.tcl_adain_fuse_f16(noises_t, noises, n_local * 4, self.h * self.w, float(alphas[i]), stream())
+            z = None
+            if i < len(sch.timesteps) - 1:     # the last SDE step has sigma_t = 0: its noise term vanishes
+                zf = torch.randn(self.n_total, 4, self.h, self.w, generator=self.rng_dev, device=self.dev, dtype=torch.float32)
+                z = zf[lo:hi].to(H16).contiguous()
+            sch.step(noises, t, x, noise=z)
+            self.unet.tome.reset_global_tokens()       # post_iter (generate_utils.py:235-238)
+        return x
+
+    # ------------------------------------------------------------------ end to end
+    def __call__(self, frames, conds, conds_t, past_flows, mask_bwds, unq_inv, n_total=None, k=None):
+        """frames: local block [n_local,3,H,W]; conds / conds_t: [2,L,768] f16 (uncond, cond) text embeddings for the xy / yt
+        passes (generate.py:553-555); past_flows / mask_bwds / unq_inv: stage-2 inputs for ALL frames (device).
+        Returns (relit frames [N,3,H,W] f32, info dict)."""
+        c, d = self.cfg, self.dist
+        self.n_total = n_total or frames.shape[0] * d.world
+        ev = lambda: (torch.cuda.synchronize(self.dev), time.perf_counter())[1]
+        t0 = ev()
+        self.prepare_data(frames)
+        concat_conds = self.vae.encode_imgs_batch(self.frames, self.batch_size)
+        t1 = ev()
+        x = self.ddim_sample(self.init_noise.clone(), conds, conds_t, concat_conds)
+        t2 = ev()
+        clean_local = self.vae.decode_latents_batch(x, self.batch_size)
+        clean = d.gather_frames(clean_local, self.n_total)
+        t3 = ev()
+        losses1 = losses2 = None
+        if c.apply_opt:
+            N = self.n_total
+            ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
+            rng = np.random.default_rng(c.seed)           # identical on every rank -> replicated stage 1/2
+            s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)
+            _, _, losses1 = post_opt.exposure_align(ds, s1, c.epochs_exposure, c.batch_size, c.exposure_lr_init, c.exposure_lr_final,
+                                                    c.lambda_dssim, c.lambda_flow)
+            t4 = ev()
+            if c.epochs > 0:
+                s2 = post_opt.make_schedule(N, c.batch_size, c.epochs, rng)
+                clean, _, losses2 = post_opt.unique_tensor_optimization(ds, unq_inv, s2, c.batch_size, c.feature_lr, c.lambda_dssim,
+                                                                        c.lambda_flow, c.lambda_tv, k=k)
+            else:
+                clean = ds.edited_images
+            t5 = ev()
+        else:
+            t4 = t5 = t3
+        self.timing = dict(encode=t1 - t0, denoise=t2 - t1, decode=t3 - t2, stage1=t4 - t3, stage2=t5 - t4, total=t5 - t0)
+        info = dict(timing=self.timing, losses_exposure=losses1, losses_unique=losses2, total_time=t5 - t0,
+                    sec_per_frame=(t5 - t0) / self.n_total, total_number_of_frames=self.n_total,
+                    max_memory_allocated=torch.cuda.max_memory_allocated(self.dev) / 1024.0 ** 2)
+        return clean, info

@@ -1,0 +1,91 @@
+"""Integer host logic of the denoising loop: chunking, yt-plane windows, decay schedule (no tensors on the data path).
+
+get_chunks        utils/VidToMe/generate_utils.py:174-205
+temporal_windows  generate.py:246-260
+alpha_schedule    generate.py:228-229
+The reference draws from the global numpy / torch CPU RNGs; here the draws come from explicit seeded streams so that
+"identical seeds" means the same choices on any device (hard part 3).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def chunks_from_draws(flen, chunk_size, rand_first, flip_draw, perm, merge_global=True, chunk_ord="mix", perm_div=4.0):
+    """Pure function of the three draws: rand_first in [0, chunk_size), flip_draw in [0,1), perm = permutation of chunk ids."""
+    first = rand_first + 1
+    bounds = [(0, min(first, flen))]
+    s = first
+    while s < flen:
+        bounds.append((s, min(s + chunk_size, flen)))
+        s += chunk_size
+    chunks = [list(range(a, b)) for a, b in bounds]
+    if flip_draw > 0.5:
+        chunks = chunks[::-1]
+    if not merge_global:
+        return chunks
+    n = len(chunks)
+    if chunk_ord == "rand":
+        order = [int(p) for p in perm]
+    elif chunk_ord == "mix":
+        randord = [int(p) for p in perm]
+        rand_len = int(n / perm_div)
+        seqord = sorted(randord[rand_len:])
+        if rand_len > 0:
+            randord = randord[:rand_len]
+            if abs(seqord[-1] - randord[-1]) < abs(seqord[0] - randord[-1]):
+                seqord = seqord[::-1]
+            order = randord + seqord
+        else:
+            order = seqord
+    else:
+        order = list(range(n))
+    return [chunks[i] for i in order]
+
+
+def n_chunks(flen, chunk_size, rand_first):
+    first = rand_first + 1
+    return 1 + max(0, math.ceil((flen - first) / chunk_size))
+
+
+class ChunkSampler:
+    """Seeded stand-in for the np.random / torch.randperm calls of get_chunks."""
+
+    def __init__(self, seed, chunk_size=4, merge_global=True, chunk_ord="mix-4"):
+        self.np_rng = np.random.RandomState(seed)
+        self.t_gen = torch.Generator(device="cpu").manual_seed(int(seed))
+        self.chunk_size, self.merge_global = chunk_size, merge_global
+        self.perm_div = float(chunk_ord.split("-")[-1]) if "-" in chunk_ord else 3.0
+        self.chunk_ord = "mix" if "mix" in chunk_ord else chunk_ord
+
+    def get_chunks(self, flen):
+        rf = int(self.np_rng.randint(0, self.chunk_size))
+        fl = float(self.np_rng.rand())
+        n = n_chunks(flen, self.chunk_size, rf)
+        perm = torch.randperm(n, generator=self.t_gen) if (self.merge_global and self.chunk_ord in ("rand", "mix")) else torch.arange(n)
+        return chunks_from_draws(flen, self.chunk_size, rf, fl, perm, self.merge_global, self.chunk_ord, self.perm_div)
+
+
+def temporal_windows(n, win):
+    """-> (window starts, overlaps): n_slices = ceil((n-1)/(win-1)); later windows overwrite then scale the overlap."""
+    n_slices = math.ceil((n - 1) / (win - 1)) if n > 1 else 1
+    if n_slices > 1:
+        total = n_slices * win - n
+        ov = total // (n_slices - 1)
+        last = ov + total % (n_slices - 1)
+        ovl = [ov] * (n_slices - 2) + [last]
+        cs = np.cumsum(ovl)
+        return [0] + [int((i + 1) * win - cs[i]) for i in range(n_slices - 1)], [int(o) for o in ovl]
+    return [0], [0]
+
+
+def alpha_schedule(alpha_t, final_factor_t, n_steps):
+    return [alpha_t * final_factor_t ** min(i / n_steps, 1) for i in range(n_steps)]
+
+
+def shard_range(n, rank, world):
+    """Contiguous frame block of `rank` (sizes differ by at most one; SURVEY 8(d) config 3: 38/38/38/38/37/37/37/37)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

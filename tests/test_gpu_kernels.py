@@ -158,7 +158,7 @@ def test_pack_unpack_adain(L):
     assert torch.equal(out[:4], xt.permute(0, 2, 3, 1))
     eps = torch.randn(8, nwin, h, 4, device="cuda", generator=g).to(H)
     noise = torch.zeros(N, 4, h, w, device="cuda", dtype=H)
-    L.tcl_unpack_cfg_f16(eps, cols, 4, 1, sl, nwin, h, w, 2.0, sl + 2, 0.5 ** 0.5, noise, st())
+    L.tcl_unpack_cfg_f16(eps, cols, 4, 1, sl, nwin, h, w, 2.0, sl + 2, 0.5 ** 0.5, nwin, noise, st())
     e = eps.float().permute(0, 3, 1, 2)                                                    # [2F, c, n, h]
     pred = e[:4] + 2.0 * (e[4:] - e[:4])                                                   # w c n h
     refn = torch.zeros(N, 4, h, w, device="cuda")

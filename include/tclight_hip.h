@@ -70,6 +70,9 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
  * in halves) % 8 == 0.  torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL. */
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st);
+/* Register caller-owned device scratch for split-K partial sums (used by tcl_gemm_f16 / tcl_conv3x3_f16 when the tile grid
+ * would leave most CUs idle).  NULL disables split-K.  All calls that use it must be issued on one stream. */
+int tcl_set_workspace(void* ws, size_t bytes);
 /* 3x3 Conv2d as implicit GEMM on NHWC: X [B,Hin,Win,Cin], W [Cout, 9*Cin] (tap-major: (ky*3+kx)*Cin + c), Y [B,Hout,Wout,Cout].
  * pad=1: padding 1 (UNet ResnetBlock2D / Downsample2D stride 2); pad=0 with stride 2: the VAE encoder's (0,1,0,1) padding.
  * Hup/Wup > 0: the input is first nearest-upsampled to Hup x Wup (Upsample2D with explicit output size), fused in the gather. */

@@ -18,6 +18,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define KV_TILE 64
 #define V_STRIDE 68   // halves: 34 dwords -> the 32 rows of a ds_read_b64 group hit 32 distinct even bank pairs
@@ -57,18 +59,80 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
     __syncthreads();
     for (int i = threadIdx.x; i < DPV * 64; i += 256) {
         int dd = i / 64, r = i % 64;
-        vt[((long)bh * DPV + dd) * Tp + t0 + r] = tile[r * st + dd];
+        _Float16 val = tile[r * st + dd];
+        if (dd == d && DPV > d) val = (t0 + r < T) ? (_Float16)1.f : (_Float16)0.f;   // ones row: the PV MFMA also yields the softmax row sums
+        vt[((long)bh * DPV + dd) * Tp + t0 + r] = val;
     }
 }
 
-template <int DP, int DPV>
-__global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
-                                               _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
-                                               int kv_div, int nqb) {
+// One 64-key tile for one wave (32 queries): S^T = K.Q^T, online softmax, O^T += V^T.P^T.
+// LROW: the row sums l come out of the PV MFMA itself through a ones-row that k_pack_vt stores at Vt row D (free padding
+// row when DPV > D), so no VALU adds are spent on them.  Rescaling of O is lazy: only when some query of the wave sees its
+// running max grow by more than 2^6 (wave-uniform branch); P then stays <= 64, far inside f16 range.
+template <int DP, int DPV, bool LROW>
+__device__ __forceinline__ void flash_tile(const _Float16* __restrict__ kt, const _Float16* __restrict__ vt, const half8 (&qf)[DP / 16],
+                                           float16v (&o)[DPV / 32], float& m, float& lsum, int ql, int hl, int kv0, int Tk, bool mask) {
+    constexpr int KS = DP + 8, NQK = DP / 16, NDT = DPV / 32;
+    float16v s[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+        const _Float16* kr = kt + (blk * 32 + ql) * KS + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(kr + ks * 16), qf[ks], s[blk], 0, 0, 0);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)mask)) {      // scalar branch: only the last tile has padded keys
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { int kv = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (__any(mx > m + 6.f)) {                     // lazy rescale (rare after the first tiles)
+        const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
+    half8 pf[2][2];
+    float ps = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - m); if (!LROW) ps += p; pf[blk][r >> 3][r & 7] = (_Float16)p; }
+    if (!LROW) lsum += ps;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 4 * hl;
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                half4 lo = *(const half4*)(vr + t * 32 * V_STRIDE), hi = *(const half4*)(vr + t * 32 * V_STRIDE + 8);
+                half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][ss], o[t], 0, 0, 0);
+            }
+        }
+}
+
+template <int D, int DP, int DPV>
+__global__ __launch_bounds__(256, 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                                  _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
+                                                  int kv_div, int nqb) {
     constexpr int KS = DP + 8;                    // K row stride (halves); (DP+8)/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KCH = KV_TILE * DP / 8, VCH = DPV * 8;           // 16-B chunks per tile
     constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
+    constexpr bool LROW = DPV > D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Ks = (_Float16*)smem;                         // [2][64][KS]
     _Float16* Vs = Ks + 2 * KV_TILE * KS;                   // [2][DPV][V_STRIDE]
@@ -86,23 +150,19 @@ __global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, 
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) qf[ks] = *(const half8*)(qrow + ks * 16);
     }
-    uint4 rk[KIT], rv[VIT];
-    auto gload = [&](int it) {
-        const _Float16* kt = kbase + (long)it * KV_TILE * DP;
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if (c < KCH) rk[i] = *(const uint4*)(kt + c * 8); }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) { int c = tid + 256 * i; if (c < VCH) rv[i] = *(const uint4*)(vbase + (long)(c >> 3) * Tkp + it * KV_TILE + (c & 7) * 8); }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if (c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(uint4*)(Ks + (buf * KV_TILE + r) * KS + c8) = rk[i]; } }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            int c = tid + 256 * i;
-            if (c < VCH) { uint2* p = (uint2*)(Vs + (buf * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p[0] = make_uint2(rv[i].x, rv[i].y); p[1] = make_uint2(rv[i].z, rv[i].w); }
-        }
-    };
+    u32x4 rkA[KIT], rvA[VIT], rkB[KIT], rvB[VIT];      // two staging sets: tile it+1 waits in one while tile it+2 is in flight
+#define FLASH_GLOAD(IT, RK, RV)                                                                                               \
+    {                                                                                                                         \
+        const _Float16* kt_ = kbase + (long)(IT) * KV_TILE * DP;                                                             \
+        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = min(tid + 256 * i, KCH - 1); RK[i] = *(const u32x4*)(kt_ + c * 8); }   /* clamped: always defined */ \
+        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = min(tid + 256 * i, VCH - 1); RV[i] = *(const u32x4*)(vbase + (long)(c >> 3) * Tkp + (IT) * KV_TILE + (c & 7) * 8); } \
+    }
+#define FLASH_SSTORE(BUF, RK, RV)                                                                                             \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if ((i + 1) * 256 <= KCH || c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(u32x4*)(Ks + ((BUF) * KV_TILE + r) * KS + c8) = RK[i]; } } \
+        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + 256 * i; if ((i + 1) * 256 <= VCH || c < VCH) { u32x2* p_ = (u32x2*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p_[0] = RV[i].xy; p_[1] = RV[i].zw; } } \
+    }
+#define FLASH_TILE(BUF, IT) flash_tile<DP, DPV, LROW>(Ks + (BUF) * KV_TILE * KS, Vs + (BUF) * DPV * V_STRIDE, qf, o, m, lsum, ql, hl, (IT) * KV_TILE, Tk, (IT) >= nfull)
 
     float16v o[NDT];
 #pragma unroll
@@ -111,67 +171,47 @@ __global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, 
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m = -1e30f, lsum = 0.f;
 
-    const int nt = Tkp / KV_TILE;
-    gload(0); sstore(0);
-    __syncthreads();
-    for (int it = 0; it < nt; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nt) gload(it + 1);
-        // ---- S^T = K . Q^T  (two 32-key blocks)
-        float16v s[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
-            const _Float16* kr = Ks + (cur * KV_TILE + blk * 32 + ql) * KS + 8 * hl;
-#pragma unroll
-            for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(kr + ks * 16), qf[ks], s[blk], 0, 0, 0);
-        }
-        if ((it + 1) * KV_TILE > Tk) {   // mask padded keys (last tile only)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
-        }
-        // ---- online softmax (this lane: one query, 32 of the tile's 64 keys; partner lane^32 holds the rest)
-        float mx = s[0][0];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        float ps = 0.f;
-        half8 pf[2][2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - mn); ps += p; pf[blk][r >> 3][r & 7] = (_Float16)p; }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int t = 0; t < NDT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const _Float16* vr = Vs + (cur * DPV + ql) * V_STRIDE + blk * 32 + 16 * ss + 4 * hl;
-#pragma unroll
-                for (int t = 0; t < NDT; ++t) {
-                    half4 lo = *(const half4*)(vr + t * 32 * V_STRIDE), hi = *(const half4*)(vr + t * 32 * V_STRIDE + 8);
-                    half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][ss], o[t], 0, 0, 0);
-                }
-            }
-        if (it + 1 < nt) sstore(cur ^ 1);
+    const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;      // tiles without padded keys
+    constexpr bool PF2 = DP <= 80;        // prefetch distance 2 (two register sets) where the register budget allows it
+    FLASH_GLOAD(0, rkA, rvA); FLASH_SSTORE(0, rkA, rvA);
+    if constexpr (PF2) {
+        if (nt > 1) FLASH_GLOAD(1, rkA, rvA);
         __syncthreads();
+        for (int it = 0; it < nt; it += 2) {
+            // even tile in LDS buffer 0; set A holds tile it+1; tile it+2 goes into set B (two iterations to land)
+            if (it + 2 < nt) FLASH_GLOAD(it + 2, rkB, rvB);
+            FLASH_TILE(0, it);
+            if (it + 1 < nt) FLASH_SSTORE(1, rkA, rvA);
+            __syncthreads();
+            if (it + 1 >= nt) break;
+            if (it + 3 < nt) FLASH_GLOAD(it + 3, rkA, rvA);
+            FLASH_TILE(1, it + 1);
+            if (it + 2 < nt) FLASH_SSTORE(0, rkB, rvB);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int it = 0; it < nt; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < nt) FLASH_GLOAD(it + 1, rkA, rvA);
+            FLASH_TILE(cur, it);
+            if (it + 1 < nt) FLASH_SSTORE(cur ^ 1, rkA, rvA);
+            __syncthreads();
+        }
     }
+#undef FLASH_TILE
+#undef FLASH_GLOAD
+#undef FLASH_SSTORE
     // ---- epilogue
-    lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.f / lsum;
+    float l;
+    if (LROW) {      // l sits in O^T row D: tile D/32, register group (D%32)/8 (D%8 == 0), lanes with hl == (D%8)/4 == 0
+        constexpr int TL = D / 32, RG = (D % 32) / 8;
+        l = o[TL][4 * RG];
+        l = __shfl(l, ql, 64);                    // broadcast from the hl == 0 half
+    } else {
+        l = lsum + __shfl_xor(lsum, 32, 64);
+    }
+    const float inv = 1.f / l;
     const int q = q0 + ql;
     if (q < Tq) {
         _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
@@ -193,17 +233,17 @@ __global__ __launch_bounds__(256) void k_flash(const _Float16* __restrict__ Qp, 
 struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
 static FlashProf g_prof;
 
-template <int DP, int DPV>
+template <int D, int DP, int DPV>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
     const size_t lds = (size_t)2 * KV_TILE * (DP + 8) * 2 + (size_t)2 * DPV * V_STRIDE * 2;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_flash<DP, DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / 128;
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
-    hipLaunchKernelGGL((k_flash<DP, DPV>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -256,9 +296,9 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, DP, kc);
         hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp, DPV);
     }
-    if (d == 40) return launch_flash<48, 64>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 80) return launch_flash<80, 96>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    return launch_flash<160, 160>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40) return launch_flash<40, 48, 64>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 80) return launch_flash<80, 80, 96>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    return launch_flash<160, 160, 160>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
 }
 
 }  // extern "C"

@@ -18,20 +18,35 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
     if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
     __syncthreads();
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
-    const long total = (long)(r1 - r0) * nchunk;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        int row = r0 + (int)(i / nchunk), ch = (int)(i % nchunk) * 8;
-        const _Float16* p = ch < C1 ? x1 + ((long)b * HW + row) * C1 + ch : x2 + ((long)b * HW + row) * C2 + (ch - C1);
-        h8 v = *(const h8*)p;
-        int g0 = ch / cpg; float s = 0.f, q = 0.f;
+    // each thread owns one 8-channel chunk (fixed groups) and walks rows: partial sums stay in registers, LDS atomics once
+    const int cw = nchunk < 256 ? nchunk : 256, rp = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    if (tr < rp)
+        for (int c0 = 0; c0 < nchunk; c0 += cw) {
+            const int chunk = c0 + tc;
+            if (chunk >= nchunk) break;
+            const int ch = chunk * 8, gf = ch / cpg;
+            int slot[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int g = (ch + j) / cpg;
-            if (g != g0) { atomicAdd(&gs[g0], s); atomicAdd(&gq[g0], q); g0 = g; s = q = 0.f; }
-            float f = (float)v[j]; s += f; q += f * f;
+            for (int j = 0; j < 8; ++j) slot[j] = (ch + j) / cpg - gf;
+            float s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0;
+            const bool first = ch < C1;
+            const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
+            const int ld = first ? C1 : C2;
+            for (int row = r0 + tr; row < r1; row += rp) {
+                h8 v = *(const h8*)(base + (long)row * ld);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = (float)v[j], f2 = f * f;
+                    s0 += slot[j] == 0 ? f : 0.f; q0 += slot[j] == 0 ? f2 : 0.f;
+                    s1 += slot[j] == 1 ? f : 0.f; q1 += slot[j] == 1 ? f2 : 0.f;
+                    s2 += slot[j] == 2 ? f : 0.f; q2 += slot[j] == 2 ? f2 : 0.f;
+                }
+            }
+            atomicAdd(&gs[gf], s0); atomicAdd(&gq[gf], q0);
+            if (slot[7] >= 1) { atomicAdd(&gs[gf + 1], s1); atomicAdd(&gq[gf + 1], q1); }
+            if (slot[7] >= 2) { atomicAdd(&gs[gf + 2], s2); atomicAdd(&gq[gf + 2], q2); }
         }
-        atomicAdd(&gs[g0], s); atomicAdd(&gq[g0], q);
-    }
     __syncthreads();
     if (threadIdx.x < G) { atomicAdd(ws + ((long)b * G + threadIdx.x) * 2, gs[threadIdx.x]); atomicAdd(ws + ((long)b * G + threadIdx.x) * 2 + 1, gq[threadIdx.x]); }
 }

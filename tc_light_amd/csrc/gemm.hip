@@ -13,6 +13,7 @@
 // stays in that XCD's L2 while W (small) is L2-resident everywhere.
 #include "common.h"
 #include "../../include/tclight_hip.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -28,19 +29,21 @@ struct ConvP {
     float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                               const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                               _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
-                                              ConvP cp, int tiles_m, int tiles_n) {
+                                              ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* As = (_Float16*)smem;                          // [2][BM][72]
-    _Float16* Bs = As + 2 * BM * LDS_STRIDE;                 // [2][BN][72]
+    _Float16* As = (_Float16*)smem;                          // [NBUF][BM][72]
+    _Float16* Bs = As + NBUF * BM * LDS_STRIDE;              // [NBUF][BN][72]
 
     // XCD-aware tile assignment
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tgrid = ((tiles_m + 7) >> 3) * 8 * tiles_n;        // blocks per K-split
+    const int split = blockIdx.x / tgrid;
+    const int bid = blockIdx.x - split * tgrid, xcd = bid & 7, j = bid >> 3;
     const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
     if (tm >= tiles_m) return;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -102,12 +105,12 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = K / BK;
-    gload(0); sstore(0);
+    const int kt0 = split * nk_per, nk = min(K / BK, kt0 + nk_per);
+    gload(kt0); sstore(NBUF == 2 ? (kt0 & 1) : 0);
     __syncthreads();
     const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = NBUF == 2 ? (kt & 1) : 0;
         if (kt + 1 < nk) gload(kt + 1);
         const _Float16* as = As + (cur * BM + wm * (BM / WM) + frow) * LDS_STRIDE + fk;
         const _Float16* bs = Bs + (cur * BN + wn * (BN / WN) + frow) * LDS_STRIDE + fk;
@@ -123,11 +126,48 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
+        if (NBUF == 1) __syncthreads();            // single buffer: everyone done reading before it is overwritten
+        if (kt + 1 < nk) sstore(NBUF == 2 ? (cur ^ 1) : 0);
         __syncthreads();
     }
 
-    // epilogue: lane holds column n = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32x32 tile
+    // ---- epilogue A (vector path): stage f16(act(acc+bias)) through LDS, then whole 16-B row chunks (+residual) to HBM
+    constexpr int CS = BN + 8;                      // staging row stride (halves); BM*CS*2 bytes <= the operand buffers
+    if (!part && (N & 7) == 0 && (ldc & 7) == 0 && (!resid || (ldr & 7) == 0)) {
+        _Float16* Cs = (_Float16*)smem;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int nl = wn * (BN / WN) + b * 32 + (lane & 31), n = n0 + nl;
+            const float bv = (bias && n < N) ? (float)bias[n] : 0.f;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int ml = wm * (BM / WM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[a][b][r] + bv;
+                    if (act == 1) v = v / (1.f + __expf(-v));
+                    Cs[(ml + (r & 3) + 8 * (r >> 2)) * CS + nl] = (_Float16)v;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, c8 = (c % CPR) * 8, m = m0 + row, n = n0 + c8;
+            if (m < M && n < N) {
+                half8 v = *(const half8*)(Cs + row * CS + c8);
+                if (resid) {
+                    half8 rv = *(const half8*)(resid + (long)m * ldr + n);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] + (float)rv[q]);
+                }
+                *(half8*)(C + (long)m * ldc + n) = v;
+            }
+        }
+        return;
+    }
+    // ---- epilogue B (scalar path; split-K partials, odd N): lane holds column n = lane&31 and rows (r&3)+8*(r>>2)+4*(lane>>5)
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int n = n0 + wn * (BN / WN) + b * 32 + (lane & 31);
@@ -140,34 +180,76 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m >= M) continue;
+                if (part) { part[((long)split * M + m) * N + n] = acc[a][b][r]; continue; }   // split-K partial (f32)
                 float v = acc[a][b][r] + bv;
                 if (act == 1) v = v / (1.f + __expf(-v));                       // SiLU
-                if (resid) v += (float)resid[(long)m * ldr + n];
+                if (resid) v = (float)(_Float16)v + (float)resid[(long)m * ldr + n];
                 C[(long)m * ldc + n] = (_Float16)v;
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+// split-K second pass: C = act(sum_s part[s] + bias) + resid
+__global__ void k_splitk_finalize(const float* __restrict__ part, int splits, const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
+                                  _Float16* __restrict__ C, int M, int N, int ldc, int ldr, int act) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N); const long m = i / N;
+        float v = bias ? (float)bias[n] : 0.f;
+        for (int sidx = 0; sidx < splits; ++sidx) v += part[(long)sidx * total + i];
+        if (act == 1) v = v / (1.f + __expf(-v));
+        if (resid) v += (float)resid[m * ldr + n];
+        C[m * ldc + n] = (_Float16)v;
+    }
+}
+
+// caller-owned scratch for split-K partials (tcl_set_workspace); all GEMMs using it must be issued on one stream
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+template <int BM, int BN, int WM, int WN, int NBUF>
 static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
                        int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const int grid = cdiv(tm, 8) * 8 * tn;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * 2;
+    const size_t lds = (size_t)NBUF * (BM + BN) * LDS_STRIDE * 2;
+    static_assert((size_t)BM * (BN + 8) * 2 <= (size_t)NBUF * (BM + BN) * LDS_STRIDE * 2, "C staging must fit");
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn);
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    // small-M / deep-K problems (the 1280-channel levels, yt-plane chunks) leave most of the 256 CUs idle: split K so that
+    // ~2 blocks per CU exist, partials in f32, deterministic second pass.
+    const int nk = K / BK;
+    int splits = 1;
+    static const int sk_tiles = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 384;
+    static const int sk_target = getenv("TCL_SPLITK_TARGET") ? atoi(getenv("TCL_SPLITK_TARGET")) : 512;
+    if (tm * tn < sk_tiles && nk >= 32 && g_ws) {     // measured: splitting K < 2048 loses to the extra pass
+        splits = min(nk / 8, cdiv(sk_target, tm * tn));
+        while (splits > 1 && (size_t)splits * M * N * 4 > g_ws_bytes) --splits;
+    }
+    const int nk_per = cdiv(nk, splits);
+    splits = cdiv(nk, nk_per);
+    float* part = splits > 1 ? g_ws : nullptr;
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NBUF>), dim3(grid * splits), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp,
+                       tm, tn, nk_per, part);
+    if (part) hipLaunchKernelGGL(k_splitk_finalize, dim3(stream_grid((long)M * N, 256, 4)), dim3(256), 0, st, part, splits, bias, resid, C, M, N, ldc, ldr, act);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    if (N % 128 == 0 || N > 512) return launch_gemm<128, 128, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-    return launch_gemm<128, 64, 4, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    static const int nbuf = getenv("TCL_GEMM_NBUF") ? atoi(getenv("TCL_GEMM_NBUF")) : 1;
+    if (N % 128 == 0 || N > 512) {
+        if (nbuf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
+    if (nbuf == 2) return launch_gemm<128, 64, 4, 1, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
 }
 
 extern "C" {
+
+int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = ws ? bytes : 0; return TCL_OK; }
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {

@@ -27,11 +27,16 @@ def _conv_w(w, dev):          # [Cout,Cin,3,3] -> [Cout, 9*Cin] tap-major
 
 class Ops:
     """Thin typed wrappers around the C ABI (allocation via torch's caching allocator, launches on the current stream)."""
+    _splitk_ws = {}
 
     def __init__(self, dev):
         self.dev = dev
         self.L = lib()
         self._gn_ws = {}
+        ws = Ops._splitk_ws.get(str(dev))
+        if ws is None:      # one split-K scratch per device, registered with the library (single compute stream)
+            ws = Ops._splitk_ws[str(dev)] = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
+            self.L.tcl_set_workspace(ws, ws.numel())
 
     def empty(self, *shape, dtype=H16):
         return torch.empty(*shape, dtype=dtype, device=self.dev)

@@ -223,3 +223,28 @@ def test_vidtome_maps_vs_oracle(L):
             assert torch.equal(a, b)
             assert torch.equal(tome.banks["blk"].cpu().float(), r["bank_new"])
         bank = tome.banks["blk"].cpu().float()       # continue the chain from the HIP bank so later rounds stay comparable
+
+
+def test_splitk_gemm_conv(L):
+    """small-M deep-K problems take the split-K path once a workspace is registered; result must match the direct path."""
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, N, K = 384, 1280, 11520
+    A = torch.randn(M, K, device="cuda", generator=g).to(H)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(H)
+    b, R = torch.randn(N, device="cuda", generator=g).to(H), torch.randn(M, N, device="cuda", generator=g).to(H)
+    C0, C1 = torch.empty(M, N, device="cuda", dtype=H), torch.empty(M, N, device="cuda", dtype=H)
+    L.tcl_set_workspace(0, 0)
+    L.tcl_gemm_f16(A, W, b, R, C0, M, N, K, K, K, N, N, 1, st())
+    L.tcl_set_workspace(ws, ws.numel())
+    L.tcl_gemm_f16(A, W, b, R, C1, M, N, K, K, K, N, N, 1, st())
+    ref = F.silu(A.float() @ W.float().t() + b.float()) + R.float()
+    assert rel(C1, ref) < 2e-3 and rel(C0, ref) < 2e-3
+    x = torch.randn(8, 4, 12, 1280, device="cuda", generator=g).to(H)
+    w = (torch.randn(1280, 9 * 1280, device="cuda", generator=g) / 107).to(H)
+    y0, y1 = torch.empty(8, 4, 12, 1280, device="cuda", dtype=H), torch.empty(8, 4, 12, 1280, device="cuda", dtype=H)
+    L.tcl_conv3x3_f16(x, w, b, 0, y1, 8, 4, 12, 1280, 1280, 1, 1, 0, 0, 0, st())
+    L.tcl_set_workspace(0, 0)
+    L.tcl_conv3x3_f16(x, w, b, 0, y0, 8, 4, 12, 1280, 1280, 1, 1, 0, 0, 0, st())
+    assert rel(y1, y0) < 1e-3
+    torch.cuda.synchronize()

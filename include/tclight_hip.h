@@ -37,7 +37,7 @@ int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, floa
  * (NULL to skip).  X, Y: `planes` contiguous h*w planes (= batch*channels). */
 size_t tcl_msssim_workspace_bytes(int planes, int h, int w);
 int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, float* value, float* gradX, void* ws, hipStream_t st);
-/* TVLoss(weight)(x) and its gradient  utils/loss_utils.py:324-340.  ws16: 16 bytes of scratch. */
+/* TVLoss(weight)(x) and its gradient  utils/loss_utils.py:324-340.  ws16: 1 KiB of scratch. */
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st);
 /* torch.optim.Adam single-tensor step (generate.py:381,483-487); g is consumed and zeroed. step counts from 1. */
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);

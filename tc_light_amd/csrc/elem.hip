@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
         for (int c0 = 0; c0 < nchunk; c0 += cw) {
             const int chunk = c0 + tc;
             if (chunk >= nchunk) break;
-            const int ch = chunk * 8, gf = ch / cpg;
-            int slot[8];
+            // cpg >= 4 (checked on the host): an 8-channel chunk touches at most two groups, split at a per-thread constant
+            const int ch = chunk * 8, gf = ch / cpg, gl = (ch + 7) / cpg;
+            float wlo[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) slot[j] = (ch + j) / cpg - gf;
-            float s0 = 0, s1 = 0, s2 = 0, q0 = 0, q1 = 0, q2 = 0;
+            for (int j = 0; j < 8; ++j) wlo[j] = ((ch + j) / cpg == gf) ? 1.f : 0.f;
+            float sa = 0, qa = 0, sl = 0, ql = 0;       // all 8 channels / the part in the first group
             const bool first = ch < C1;
             const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
             const int ld = first ? C1 : C2;
@@ -38,14 +39,11 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float f = (float)v[j], f2 = f * f;
-                    s0 += slot[j] == 0 ? f : 0.f; q0 += slot[j] == 0 ? f2 : 0.f;
-                    s1 += slot[j] == 1 ? f : 0.f; q1 += slot[j] == 1 ? f2 : 0.f;
-                    s2 += slot[j] == 2 ? f : 0.f; q2 += slot[j] == 2 ? f2 : 0.f;
+                    sa += f; qa += f2; sl += f * wlo[j]; ql += f2 * wlo[j];
                 }
             }
-            atomicAdd(&gs[gf], s0); atomicAdd(&gq[gf], q0);
-            if (slot[7] >= 1) { atomicAdd(&gs[gf + 1], s1); atomicAdd(&gq[gf + 1], q1); }
-            if (slot[7] >= 2) { atomicAdd(&gs[gf + 2], s2); atomicAdd(&gq[gf + 2], q2); }
+            atomicAdd(&gs[gf], sl); atomicAdd(&gq[gf], ql);
+            if (gl != gf) { atomicAdd(&gs[gl], sa - sl); atomicAdd(&gq[gl], qa - ql); }
         }
     __syncthreads();
     if (threadIdx.x < G) { atomicAdd(ws + ((long)b * G + threadIdx.x) * 2, gs[threadIdx.x]); atomicAdd(ws + ((long)b * G + threadIdx.x) * 2 + 1, gq[threadIdx.x]); }
@@ -344,7 +342,7 @@ size_t tcl_groupnorm_workspace_bytes(int B, int C) { return (size_t)B * 64 * 2 *
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {
     const int C = C1 + C2;
-    TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C1 % 8 == 0 && C2 % 8 == 0);
+    TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C / groups >= 4 && C1 % 8 == 0 && C2 % 8 == 0);
     TCL_CHECK_ARG(C2 == 0 || x2);
     float* sums = (float*)ws; float* coef = sums + (size_t)B * 64 * 2;
     if (hipMemsetAsync(sums, 0, (size_t)B * groups * 2 * 4, st) != hipSuccess) return TCL_ELAUNCH;

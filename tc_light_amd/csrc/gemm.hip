@@ -8,7 +8,11 @@
 //
 // Tiling: BMxBNx64 block tile, 256 threads = WMxWN waves, each wave (BM/WM)x(BN/WN) out of 32x32x16 f16
 // MFMAs; operands staged global -> VGPR -> LDS (16 B per lane, rows padded to 72 halves = 9 slots so the
-// 16-lane ds_read_b128 groups are conflict-free), double-buffered with one barrier per K-step.
+// 16-lane ds_read_b128 groups are conflict-free).  ONE LDS buffer (36.8 KB) + register prefetch of the next K-step and
+// __launch_bounds__(256, 3): measured on MI355X, 3 resident blocks per CU hide latency better than a second LDS buffer or a
+// deeper register pipeline (PF = 2/3 drop to 2 waves/SIMD and lose 10-40 %).  The epilogue stages f16 tiles through LDS so
+// stores (and residual loads) are whole 16-B row chunks.  Small-M / deep-K problems (1280-channel levels, yt-plane chunks)
+// are split along K into f32 partials with a deterministic second pass.
 // Blocks are laid out XCD-aware: XCD x owns M-tiles == x (mod 8) and walks N-tiles fastest so the A tile
 // stays in that XCD's L2 while W (small) is L2-resident everywhere.
 #include "common.h"
@@ -17,6 +21,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define BK 64
 #define LDS_STRIDE 72  // halves
@@ -29,16 +34,16 @@ struct ConvP {
     float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
 };
 
-template <int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                               const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                               _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
                                               ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* As = (_Float16*)smem;                          // [NBUF][BM][72]
-    _Float16* Bs = As + NBUF * BM * LDS_STRIDE;              // [NBUF][BN][72]
+    _Float16* As = (_Float16*)smem;                          // [BM][72]   (single LDS buffer, register prefetch)
+    _Float16* Bs = As + BM * LDS_STRIDE;                     // [BN][72]
 
     // XCD-aware tile assignment
     const int tgrid = ((tiles_m + 7) >> 3) * 8 * tiles_n;        // blocks per K-split
@@ -67,35 +72,35 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) { int n = n0 + (tid >> 3) + 32 * i; w_ok[i] = n < N; wp[i] = W + (long)(w_ok[i] ? n : 0) * ldw + kc8; }
 
-    uint4 ra[A_IT], rb[B_IT];
-    auto gload = [&](int kt) {
-        const int k0 = kt * BK;
-        int tap_dy = 0, tap_dx = 0, c0 = k0;
-        if (cp.conv) { int tap = k0 / cp.Cin; c0 = k0 - tap * cp.Cin; tap_dy = tap / 3; tap_dx = tap - tap_dy * 3; }
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a_ok[i]) {
-                if (!cp.conv) v = *(const uint4*)(A + a_off[i] + k0 + kc8);
-                else {
-                    int iy = a_oy[i] + tap_dy, ix = a_ox[i] + tap_dx;
-                    if (iy >= 0 && iy < cp.Hup && ix >= 0 && ix < cp.Wup) {
-                        if (cp.Hup != cp.Hin) { iy = min((int)floorf(iy * cp.sy), cp.Hin - 1); ix = min((int)floorf(ix * cp.sx), cp.Win - 1); }
-                        v = *(const uint4*)(A + a_off[i] + ((long)iy * cp.Win + ix) * cp.Cin + c0 + kc8);
-                    }
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = w_ok[i] ? *(const uint4*)(wp[i] + k0) : make_uint4(0, 0, 0, 0);
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) *(uint4*)(As + (buf * BM + (tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *(uint4*)(Bs + (buf * BN + (tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = rb[i];
-    };
+    // PF register staging sets (native vector type: hipcc keeps HIP's uint4 struct arrays in scratch): tile t+1..t+PF in
+    // flight while tile t (already in the single LDS buffer) is consumed.
+    u32x4 ra[PF][A_IT], rb[PF][B_IT];
+#define GEMM_GLOAD(KT, S)                                                                                                     \
+    {                                                                                                                         \
+        const int k0_ = (KT) * BK;                                                                                            \
+        int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
+        if (cp.conv) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }          \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                                   \
+            u32x4 v_ = {0u, 0u, 0u, 0u};                                                                                      \
+            if (a_ok[i]) {                                                                                                    \
+                if (!cp.conv) v_ = *(const u32x4*)(A + a_off[i] + k0_ + kc8);                                                 \
+                else {                                                                                                        \
+                    int iy_ = a_oy[i] + tdy_, ix_ = a_ox[i] + tdx_;                                                           \
+                    if (iy_ >= 0 && iy_ < cp.Hup && ix_ >= 0 && ix_ < cp.Wup) {                                               \
+                        if (cp.Hup != cp.Hin) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
+                        v_ = *(const u32x4*)(A + a_off[i] + ((long)iy_ * cp.Win + ix_) * cp.Cin + c0_ + kc8);                 \
+                    }                                                                                                         \
+                }                                                                                                             \
+            }                                                                                                                 \
+            ra[S][i] = v_;                                                                                                    \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) { u32x4 z_ = {0u, 0u, 0u, 0u}; rb[S][i] = w_ok[i] ? *(const u32x4*)(wp[i] + k0_) : z_; } \
+    }
+#define GEMM_SSTORE(S)                                                                                                        \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) *(u32x4*)(As + ((tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = ra[S][i]; \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) *(u32x4*)(Bs + ((tid >> 3) + 32 * i) * LDS_STRIDE + kc8) = rb[S][i]; \
+    }
 
     float16v acc[MT][NT];
 #pragma unroll
@@ -106,30 +111,40 @@ __global__ __launch_bounds__(256) void k_gemm(const _Float16* __restrict__ A, co
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int kt0 = split * nk_per, nk = min(K / BK, kt0 + nk_per);
-    gload(kt0); sstore(NBUF == 2 ? (kt0 & 1) : 0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kt0 + u < nk) GEMM_GLOAD(kt0 + u, u);
+    GEMM_SSTORE(0);
     __syncthreads();
     const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = NBUF == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nk) gload(kt + 1);
-        const _Float16* as = As + (cur * BM + wm * (BM / WM) + frow) * LDS_STRIDE + fk;
-        const _Float16* bs = Bs + (cur * BN + wn * (BN / WN) + frow) * LDS_STRIDE + fk;
+    const _Float16* as = As + (wm * (BM / WM) + frow) * LDS_STRIDE + fk;
+    const _Float16* bs = Bs + (wn * (BN / WN) + frow) * LDS_STRIDE + fk;
+    for (int kt = kt0; kt < nk; kt += PF) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            half8 fa[MT], fb[NT];
+        for (int u = 0; u < PF; ++u) {
+            const int t = kt + u;                    // tile t is in LDS; set u is free, sets u+1.. hold tiles t+1..
+            if (t < nk) {
+                if (t + PF < nk) GEMM_GLOAD(t + PF, u);
 #pragma unroll
-            for (int a = 0; a < MT; ++a) fa[a] = *(const half8*)(as + a * 32 * LDS_STRIDE + ks * 16);
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    half8 fa[MT], fb[NT];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) fb[b] = *(const half8*)(bs + b * 32 * LDS_STRIDE + ks * 16);
+                    for (int a = 0; a < MT; ++a) fa[a] = *(const half8*)(as + a * 32 * LDS_STRIDE + ks * 16);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+                    for (int b = 0; b < NT; ++b) fb[b] = *(const half8*)(bs + b * 32 * LDS_STRIDE + ks * 16);
 #pragma unroll
-                for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < MT; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                }
+                __syncthreads();                     // everyone done reading the buffer before it is overwritten
+                if (t + 1 < nk) GEMM_SSTORE((u + 1) % PF);
+                __syncthreads();
+            }
         }
-        if (NBUF == 1) __syncthreads();            // single buffer: everyone done reading before it is overwritten
-        if (kt + 1 < nk) sstore(NBUF == 2 ? (cur ^ 1) : 0);
-        __syncthreads();
     }
+#undef GEMM_GLOAD
+#undef GEMM_SSTORE
 
     // ---- epilogue A (vector path): stage f16(act(acc+bias)) through LDS, then whole 16-B row chunks (+residual) to HBM
     constexpr int CS = BN + 8;                      // staging row stride (halves); BM*CS*2 bytes <= the operand buffers
@@ -208,15 +223,15 @@ __global__ void k_splitk_finalize(const float* __restrict__ part, int splits, co
 static float* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int PF>
 static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
                        int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     const int grid = cdiv(tm, 8) * 8 * tn;
-    const size_t lds = (size_t)NBUF * (BM + BN) * LDS_STRIDE * 2;
-    static_assert((size_t)BM * (BN + 8) * 2 <= (size_t)NBUF * (BM + BN) * LDS_STRIDE * 2, "C staging must fit");
+    const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * 2;
+    static_assert((size_t)BM * (BN + 8) * 2 <= (size_t)(BM + BN) * LDS_STRIDE * 2, "C staging must fit");
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     // small-M / deep-K problems (the 1280-channel levels, yt-plane chunks) leave most of the 256 CUs idle: split K so that
     // ~2 blocks per CU exist, partials in f32, deterministic second pass.
     const int nk = K / BK;
@@ -230,7 +245,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     const int nk_per = cdiv(nk, splits);
     splits = cdiv(nk, nk_per);
     float* part = splits > 1 ? g_ws : nullptr;
-    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NBUF>), dim3(grid * splits), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp,
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, PF>), dim3(grid * splits), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp,
                        tm, tn, nk_per, part);
     if (part) hipLaunchKernelGGL(k_splitk_finalize, dim3(stream_grid((long)M * N, 256, 4)), dim3(256), 0, st, part, splits, bias, resid, C, M, N, ldc, ldr, act);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
@@ -238,12 +253,14 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
 
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    static const int nbuf = getenv("TCL_GEMM_NBUF") ? atoi(getenv("TCL_GEMM_NBUF")) : 1;
+    static const int pf = getenv("TCL_GEMM_PF") ? atoi(getenv("TCL_GEMM_PF")) : 1;       // register prefetch distance (tiles)
     if (N % 128 == 0 || N > 512) {
-        if (nbuf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        if (pf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        if (pf == 3) return launch_gemm<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     }
-    if (nbuf == 2) return launch_gemm<128, 64, 4, 1, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    if (pf == 2) return launch_gemm<128, 64, 4, 1, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    if (pf == 3) return launch_gemm<128, 64, 4, 1, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
 }
 

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #define SH_C0 0.28209479177387814f
+#define ACC_SLOTS 32   // loss accumulators: [ACC_SLOTS][4] floats = {l1, tv_h, tv_w, flow}
 #define TW 32
 #define TH 16
 #define HALO 10
@@ -325,8 +326,9 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
     }
     float r0 = block_sum(s_l1, red), r1 = block_sum(s_h, red), r2 = block_sum(s_w, red);
     if (threadIdx.x == 0) {
-        if (coef_l1 != 0.f) atomicAdd(acc + 0, r0);
-        if (coef_tvh != 0.f) { atomicAdd(acc + 1, r1); atomicAdd(acc + 2, r2); }
+        float* a = acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4;     // spread same-address atomics over slots
+        if (coef_l1 != 0.f) atomicAdd(a + 0, r0);
+        if (coef_tvh != 0.f) { atomicAdd(a + 1, r1); atomicAdd(a + 2, r2); }
     }
 }
 // flow-consistency term (generate.py:420-427): warp(pre)*m vs img*m, fwd + bwd fused.
@@ -376,14 +378,15 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
         }
     }
     float r = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc + 3, r);
+    if (threadIdx.x == 0) atomicAdd(acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4 + 3, r);
 }
 // loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
 __global__ void k_loss_finalize(float* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
                                 float c_tvh, float c_tvw, float* loss_out) {
-    float l = w_photo * (c_l1 * acc[0] + *ms_term) + w_flow * acc[3] * inv_cnt_flow + c_tvh * acc[1] + c_tvw * acc[2];
-    *loss_out = l;
-    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < ACC_SLOTS; ++sidx)
+        for (int k = 0; k < 4; ++k) { a[k] += acc[sidx * 4 + k]; acc[sidx * 4 + k] = 0.f; }
+    *loss_out = w_photo * (c_l1 * a[0] + *ms_term) + w_flow * a[3] * inv_cnt_flow + c_tvh * a[1] + c_tvw * a[2];
 }
 
 // ---------------------------------------------------------------- optimiser / init
@@ -515,11 +518,11 @@ int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, f
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st) {
     TCL_CHECK_ARG(x && value && grad && ws16 && b > 0);
     float* acc = (float*)ws16;
-    if (hipMemsetAsync(acc, 0, 16, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(acc, 0, ACC_SLOTS * 16 + 4, st) != hipSuccess) return TCL_ELAUNCH;
     float ch = weight * 2.f / ((float)c * (h - 1) * w) / b, cw = weight * 2.f / ((float)c * h * (w - 1)) / b;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(h * w, b * c), dim3(256), 0, st, x, (const float*)nullptr, (const int*)nullptr,
                        (const float*)nullptr, 0, 0, h, w, 0.f, ch, cw, grad, acc);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, acc, acc + 3 /* reads 0 */, 0.f, 0.f, 0.f, 0.f, ch, cw, value);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, acc, acc + ACC_SLOTS * 4 /* a zero */, 0.f, 0.f, 0.f, 0.f, ch, cw, value);
     TCL_LAUNCH_RET();
 }
 
@@ -529,7 +532,7 @@ static StageWs carve_stage(char* base, int b, int h, int w) {
     StageWs S; size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
     size_t P = (size_t)h * w;
-    S.cat = (float*)take(2 * b * 3 * P * 4); S.gcat = (float*)take(2 * b * 3 * P * 4); S.acc = (float*)take(64);
+    S.cat = (float*)take(2 * b * 3 * P * 4); S.gcat = (float*)take(2 * b * 3 * P * 4); S.acc = (float*)take(ACC_SLOTS * 16);
     S.cidx = (int*)take(2 * b * 4);
     size_t msb = carve_ms(nullptr, b * 3, h, w).bytes;
     char* mp = take(msb);
@@ -556,7 +559,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
     StageWs S = carve_stage((char*)ws, batch, H, W);
     const size_t P = (size_t)H * W;
     const int total_iters = epochs * N / batch, per_epoch = iters_per_epoch;
-    if (hipMemsetAsync(S.acc, 0, 64, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;
@@ -593,7 +596,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
     StageWs S = carve_stage((char*)ws, batch, H, W);
     const size_t P = (size_t)H * W;
     const float lr = feature_lr * (float)batch / (float)N;
-    if (hipMemsetAsync(S.acc, 0, 64, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;

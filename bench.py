@@ -56,9 +56,11 @@ def cpu_baseline(sd_unet, H, W, n_frames, n_steps, multi_axis, flops_path1, cfg)
     from oracle import path2 as O2
     from oracle import sd15 as OS
     import synth
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 64)             # torch CPU kernels stop scaling (and oversubscribe) beyond this on the GPU hosts
     torch.set_num_threads(cores)
-    h, w = H // 8, W // 8
+    # bounded sample (~10-30 s): the UNet on ONE frame at half the latent resolution, stage 2 on 2 frames at half resolution;
+    # scaled to the workload by algorithmic FLOPs (path 1) and by pixels x iterations (path 2).
+    h, w = H // 16, W // 16
     g = np.random.default_rng(0)
     x = torch.from_numpy(g.standard_normal((2, 8, h, w)).astype(np.float32))
     text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32))
@@ -68,18 +70,19 @@ def cpu_baseline(sd_unet, H, W, n_frames, n_steps, multi_axis, flops_path1, cfg)
     t_unet = time.perf_counter() - t0
     fl = unet_flops_unmerged(2, h, w, 77)      # same accounting as UNetEngine._fl (B=2, F=1, no merging)
     cpu_rate = fl / t_unet
-    d = synth.video_clip(3, H, W, seed=1)
-    inv, _ = synth.track_ids(3, H, W, seed=3)
+    H2, W2 = max(H // 2, 176), max(W // 2, 176)
+    d = synth.video_clip(3, H2, W2, seed=1)
+    inv, _ = synth.track_ids(3, H2, W2, seed=3)
     bts = [torch.tensor([1, 2])]
     t0 = time.perf_counter()
     O2.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, 2)
-    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]            # per 16-frame iteration
+    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"] * (H * W) / (H2 * W2)     # per full-size 16-frame iteration
     iters = (cfg["epochs_exposure"] + cfg["epochs"]) * -(-n_frames // cfg["batch_size"])
     total = flops_path1 / cpu_rate + iters * t_it2
     return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle UNet forward on 1 frame {W}x{H} (batch 2, {fl / 1e12:.2f} TFLOP in {t_unet:.1f} s = {cpu_rate / 1e12:.3f} TFLOP/s) "
-                       f"+ 1 oracle stage-2 iteration on 2 frames ({t_it2:.1f} s per 16-frame iteration); extrapolated as "
-                       f"path-1 algorithmic FLOPs / CPU rate + {iters} optimiser iterations")
+                sample=f"oracle UNet forward on 1 frame at latent {w}x{h} (batch 2, {fl / 1e12:.2f} TFLOP in {t_unet:.1f} s = {cpu_rate / 1e12:.3f} TFLOP/s) "
+                       f"+ 1 oracle stage-2 iteration on 2 frames {W2}x{H2} ({t_it2:.1f} s per full-size 16-frame iteration); extrapolated as "
+                       f"path-1 algorithmic FLOPs ({flops_path1 / 1e15:.2f} PFLOP) / CPU rate + {iters} optimiser iterations")
 
 
 def unet_flops_unmerged(B, h, w, L):

@@ -151,6 +151,17 @@ int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, cons
 /* h[b][i] += y[b][map[i]]  (unmerge + residual add, patch.py:178-179). */
 int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st);
 
+/* ---- stage-2 input producer ---- */
+/* get_soft_mask_bwds  utils/flow_utils.py:40-54: img [N,3,H,W], fwd/past flows [N,2,H,W] -> mask [N,1,H,W];
+ * thr_abs = org_images.max() * diff_threshold. */
+int tcl_soft_mask_bwds(const float* img, const float* fwd, const float* past, int N, int H, int W, float alpha, float beta, float thr_abs,
+                       float* mask, hipStream_t st);
+/* get_flowid  utils/flow_utils.py:56-93: ids int32 [N,H,W]; *last_id (device int) ends as the number of ids;
+ * thr_abs = frames.max() * rgb_threshold.  Conflicting writes: the largest source index wins (the reference's CPU order). */
+size_t tcl_flowid_workspace_bytes(int H, int W);
+int tcl_flowid(const float* frames, const float* fwd_flows, const float* masks, int N, int H, int W, float thr_abs, int* ids, int* last_id,
+               void* ws, hipStream_t st);
+
 /* Measurement aid (bench.py roofline leg): bracket every flash-kernel launch (head_dim == dfilter, 0 = all) with HIP events
  * on its own stream; _end returns the summed kernel time, the algorithmic FLOPs 4*B*H*Tq*Tk*d and the launch count. */
 int tcl_flash_profile_begin(int dfilter);

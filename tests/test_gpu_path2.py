@@ -134,3 +134,17 @@ def test_full_size_properties(ops):
     ds = ops.OptDataset(ed, d["past_flows"], d["masks"], device="cuda")
     out, feat, _ = ops.unique_tensor_optimization(ds, inv, np.zeros((0, 2), np.int32), batch_size=2, k=3 * h * w)
     assert (out - ed).abs().max() < 1e-6
+
+
+def test_producer_masks_and_ids(ops, golden):
+    """Stage-2 input producer vs the reference goldens: soft masks to 2e-5, flow ids bit-exact."""
+    from tc_light_amd import flow_ids
+    g = golden("path2")
+    d5 = synth.video_clip(5, 48, 64, seed=21, shift=(1.0, 0.0), jitter=0.0)
+    fwd = -d5["past_flows"].roll(-1, 0)
+    fwd[-1] = 0
+    sm = flow_ids.get_soft_mask_bwds(d5["frames"].cuda(), fwd.cuda(), d5["past_flows"].cuda(), alpha=0.5)
+    np.testing.assert_allclose(sm.cpu().numpy(), g["softmask"], atol=2e-5)
+    ids, k = flow_ids.get_flowid(d5["frames"].cuda(), fwd.cuda(), torch.from_numpy(g["softmask"]).cuda(), rgb_threshold=0.01)
+    assert np.array_equal(ids.cpu().numpy().astype(np.int64), g["flowid"])
+    assert k == int(g["flowid"].max()) + 1

@@ -30,7 +30,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=30, help="frames per GPU")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=960)
@@ -129,12 +129,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (tc_light_amd has no CPU fallback)")
+    local = local % torch.cuda.device_count()          # (lets a 2-rank gloo dry run share one GPU; one rank per GPU otherwise)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TCL_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
 

@@ -14,6 +14,7 @@
 //         Block id -> head = id % H so that each head's K/V panel lives in one XCD's L2.
 #include "common.h"
 #include "../../include/tclight_hip.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -124,14 +125,15 @@ __device__ __forceinline__ void flash_tile(const _Float16* __restrict__ kt, cons
         }
 }
 
-template <int D, int DP, int DPV>
-__global__ __launch_bounds__(256, 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+template <int D, int DP, int DPV, int NW>
+__global__ __launch_bounds__(NW * 64, (DP <= 48 && NW == 4) ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb) {
     constexpr int KS = DP + 8;                    // K row stride (halves); (DP+8)/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KCH = KV_TILE * DP / 8, VCH = DPV * 8;           // 16-B chunks per tile
-    constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
+    constexpr int NT_ = NW * 64;                                   // threads per block (NW waves x 32 query rows each)
+    constexpr int KIT = (KCH + NT_ - 1) / NT_, VIT = (VCH + NT_ - 1) / NT_;
     constexpr bool LROW = DPV > D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* Ks = (_Float16*)smem;                         // [2][64][KS]
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_flash(const _Float16* __restrict__ Q
 
     const int bid = blockIdx.x, head = bid % H, qb = (bid / H) % nqb, b = bid / (H * nqb);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hl = lane >> 5, ql = lane & 31;
-    const int q0 = qb * 128 + wid * 32;
+    const int q0 = qb * (NW * 32) + wid * 32;
     const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
     const _Float16* kbase = Kp + kbh * Tkp * DP;
     const _Float16* vbase = Vt + kbh * DPV * Tkp;
@@ -154,13 +156,13 @@ __global__ __launch_bounds__(256, 2) void k_flash(const _Float16* __restrict__ Q
 #define FLASH_GLOAD(IT, RK, RV)                                                                                               \
     {                                                                                                                         \
         const _Float16* kt_ = kbase + (long)(IT) * KV_TILE * DP;                                                             \
-        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = min(tid + 256 * i, KCH - 1); RK[i] = *(const u32x4*)(kt_ + c * 8); }   /* clamped: always defined */ \
-        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = min(tid + 256 * i, VCH - 1); RV[i] = *(const u32x4*)(vbase + (long)(c >> 3) * Tkp + (IT) * KV_TILE + (c & 7) * 8); } \
+        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = min(tid + NT_ * i, KCH - 1); RK[i] = *(const u32x4*)(kt_ + c * 8); }   /* clamped: always defined */ \
+        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = min(tid + NT_ * i, VCH - 1); RV[i] = *(const u32x4*)(vbase + (long)(c >> 3) * Tkp + (IT) * KV_TILE + (c & 7) * 8); } \
     }
 #define FLASH_SSTORE(BUF, RK, RV)                                                                                             \
     {                                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = tid + 256 * i; if ((i + 1) * 256 <= KCH || c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(u32x4*)(Ks + ((BUF) * KV_TILE + r) * KS + c8) = RK[i]; } } \
-        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + 256 * i; if ((i + 1) * 256 <= VCH || c < VCH) { u32x2* p_ = (u32x2*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p_[0] = RV[i].xy; p_[1] = RV[i].zw; } } \
+        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= KCH || c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(u32x4*)(Ks + ((BUF) * KV_TILE + r) * KS + c8) = RK[i]; } } \
+        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= VCH || c < VCH) { u32x2* p_ = (u32x2*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p_[0] = RV[i].xy; p_[1] = RV[i].zw; } } \
     }
 #define FLASH_TILE(BUF, IT) flash_tile<DP, DPV, LROW>(Ks + (BUF) * KV_TILE * KS, Vs + (BUF) * DPV * V_STRIDE, qf, o, m, lsum, ql, hl, (IT) * KV_TILE, Tk, (IT) >= nfull)
 
@@ -233,17 +235,17 @@ __global__ __launch_bounds__(256, 2) void k_flash(const _Float16* __restrict__ Q
 struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
 static FlashProf g_prof;
 
-template <int D, int DP, int DPV>
+template <int D, int DP, int DPV, int NW>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
     const size_t lds = (size_t)2 * KV_TILE * (DP + 8) * 2 + (size_t)2 * DPV * V_STRIDE * 2;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    const int nqb = Tqp / 128;
+    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / (NW * 32);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, NW>), dim3(B * H * nqb), dim3(NW * 64), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -271,7 +273,7 @@ int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches)
 }
 
 // panel sizes: Tqp = ceil128(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d)
-size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 128) * rup(d, 16) * 2 + 256; }
+size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 256) * rup(d, 16) * 2 + 256; }
 size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
     return ((size_t)Bkv * H * rup(Tk, 64) * rup(d, 16) + (size_t)Bkv * H * rup(d, 32) * rup(Tk, 64)) * 2 + 256;
 }
@@ -285,7 +287,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
     TCL_CHECK_ARG(d == 40 || d == 80 || d == 160);
     TCL_CHECK_ARG(!pack_kv || (k && v));
-    const int Tqp = rup(Tq, 128), Tkp = rup(Tk, 64), DP = rup(d, 16), DPV = rup(d, 32), Bkv = B / kv_div;
+    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), DPV = rup(d, 32), Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
     _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (size_t)Bkv * H * Tkp * DP;
@@ -296,9 +298,13 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, DP, kc);
         hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp, DPV);
     }
-    if (d == 40) return launch_flash<40, 48, 64>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 80) return launch_flash<80, 80, 96>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    return launch_flash<160, 160, 160>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    static const int nw8 = getenv("TCL_FLASH_NW") ? atoi(getenv("TCL_FLASH_NW")) == 8 : 0;
+    const bool big = nw8 && Tq >= 2048;          // 8-wave blocks (256 query rows) halve the K/V traffic per query on long sequences
+    if (d == 40) return big ? launch_flash<40, 48, 64, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                            : launch_flash<40, 48, 64, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 80) return big ? launch_flash<80, 80, 96, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                            : launch_flash<80, 80, 96, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    return launch_flash<160, 160, 160, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
 }
 
 }  // extern "C"

@@ -166,6 +166,20 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
             }
         }
         __syncthreads();
+        if (act == 2) {     // GEGLU (diffusers GEGLU, ff.net.0): the tile holds [a (BN/2) | gate (BN/2)] of the same output columns
+            constexpr int CPH = BN / 16;
+#pragma unroll
+            for (int i = 0; i < BM * CPH / 256; ++i) {
+                const int c = tid + 256 * i, row = c / CPH, c8 = (c % CPH) * 8, m = m0 + row, n = (n0 >> 1) + c8;
+                if (m < M && n < (N >> 1)) {
+                    half8 va = *(const half8*)(Cs + row * CS + c8), vg = *(const half8*)(Cs + row * CS + BN / 2 + c8);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                    *(half8*)(C + (long)m * ldc + n) = va;
+                }
+            }
+            return;
+        }
         constexpr int CPR = BN / 8;
 #pragma unroll
         for (int i = 0; i < BM * CPR / 256; ++i) {
@@ -238,7 +252,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     int splits = 1;
     static const int sk_tiles = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 384;
     static const int sk_target = getenv("TCL_SPLITK_TARGET") ? atoi(getenv("TCL_SPLITK_TARGET")) : 512;
-    if (tm * tn < sk_tiles && nk >= 32 && g_ws) {     // measured: splitting K < 2048 loses to the extra pass
+    if (tm * tn < sk_tiles && nk >= 32 && g_ws && act != 2) {     // measured: splitting K < 2048 loses to the extra pass
         splits = min(nk / 8, cdiv(sk_target, tm * tn));
         while (splits > 1 && (size_t)splits * M * N * 4 > g_ws_bytes) --splits;
     }
@@ -254,6 +268,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     static const int pf = getenv("TCL_GEMM_PF") ? atoi(getenv("TCL_GEMM_PF")) : 1;       // register prefetch distance (tiles)
+    if (act == 2 && (N % 128 != 0 || (N & 15) || (ldc & 7) || resid)) return TCL_EINVAL;  // GEGLU epilogue: 128-wide [a|gate] tiles only
     if (N % 128 == 0 || N > 512) {
         if (pf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         if (pf == 3) return launch_gemm<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
@@ -270,7 +285,7 @@ int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = 
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {
-    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 1);
+    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 2);
     ConvP cp = {};
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
                     ldw, ldc, ldr, act, cp, st);

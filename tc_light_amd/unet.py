@@ -21,6 +21,13 @@ def _dev(t, dev):
     return t.to(device=dev, dtype=H16).contiguous()
 
 
+def _geglu_rows(w):
+    """ff.net.0.proj rows [value (D) | gate (D)] -> 128-row groups [64 value | 64 matching gate] for the fused GEGLU epilogue."""
+    D = w.shape[0] // 2
+    idx = torch.arange(D).reshape(-1, 64)
+    return w[torch.cat([idx, idx + D], dim=1).reshape(-1)]
+
+
 def _conv_w(w, dev):          # [Cout,Cin,3,3] -> [Cout, 9*Cin] tap-major
     return _dev(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), dev)
 
@@ -45,9 +52,10 @@ class Ops:
         if N is None:
             N, K = w.shape
         M = M if M is not None else a.numel() // K
-        c = out if out is not None else self.empty(M, N)
+        No = N // 2 if act == 2 else N                      # act 2 = fused GEGLU: output is [M, N/2]
+        c = out if out is not None else self.empty(M, No)
         self.L.tcl_gemm_f16(a, w, bias if bias is not None else 0, resid if resid is not None else 0, c, M, N, K,
-                            lda or K, ldw or K, ldc or N, N, act, stream())
+                            lda or K, ldw or K, ldc or No, N, act, stream())
         return c
 
     def conv3x3(self, x, B, Hh, Ww, cin, w, bias, resid=None, stride=1, pad=1, up=None):
@@ -137,7 +145,7 @@ class UNetEngine:
                 q2=_dev(sd[t + "attn2.to_q.weight"], d),
                 kv2=_dev(torch.cat([sd[t + "attn2.to_k.weight"], sd[t + "attn2.to_v.weight"]]), d),
                 o2=(_dev(sd[t + "attn2.to_out.0.weight"], d), _dev(sd[t + "attn2.to_out.0.bias"], d)),
-                ff1=(_dev(sd[t + "ff.net.0.proj.weight"], d), _dev(sd[t + "ff.net.0.proj.bias"], d)),
+                ff1=(_dev(_geglu_rows(sd[t + "ff.net.0.proj.weight"]), d), _dev(_geglu_rows(sd[t + "ff.net.0.proj.bias"]), d)),
                 ff2=(_dev(sd[t + "ff.net.2.weight"], d), _dev(sd[t + "ff.net.2.bias"], d)),
                 text_kv={})
         for i in range(3):
@@ -240,9 +248,7 @@ class UNetEngine:
         self._fl(2.0 * M * C * C * 2 + 4.0 * M * Lt * C)
         # ---- GEGLU feed-forward
         n3 = o.layernorm(h, *blk["ln"][2], M, C)
-        f1 = o.gemm(n3, blk["ff1"][0], blk["ff1"][1])
-        f2 = o.empty(M, 4 * C)
-        L.tcl_geglu_f16(f1, f2, M, 4 * C, stream())
+        f2 = o.gemm(n3, blk["ff1"][0], blk["ff1"][1], act=2)            # Linear(C -> 8C) + GEGLU fused in the GEMM epilogue -> [M, 4C]
         h = o.gemm(f2, blk["ff2"][0], blk["ff2"][1], resid=h)
         self._fl(2.0 * M * C * C * 12)
         return o.gemm(h, blk["pout"][0], blk["pout"][1], resid=x)

@@ -248,3 +248,16 @@ def test_splitk_gemm_conv(L):
     L.tcl_conv3x3_f16(x, w, b, 0, y0, 8, 4, 12, 1280, 1280, 1, 1, 0, 0, 0, st())
     assert rel(y1, y0) < 1e-3
     torch.cuda.synchronize()
+
+
+def test_gemm_fused_geglu(L):
+    from tc_light_amd.unet import _geglu_rows
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, C = 777, 320
+    A = torch.randn(M, C, device="cuda", generator=g).to(H)
+    W = (torch.randn(8 * C, C, device="cuda", generator=g) / C ** 0.5).to(H)
+    b = torch.randn(8 * C, device="cuda", generator=g).to(H)
+    out = torch.empty(M, 4 * C, device="cuda", dtype=H)
+    L.tcl_gemm_f16(A, _geglu_rows(W).contiguous(), _geglu_rows(b).contiguous(), 0, out, M, 8 * C, C, C, C, 4 * C, 8 * C, 2, st())
+    f = A.float() @ W.float().t() + b.float()
+    assert rel(out, f[:, :4 * C] * F.gelu(f[:, 4 * C:])) < 2e-3

@@ -31,8 +31,9 @@ int tcl_warp_flow_bwd(const float* gout, const float* flow, float* gimg, int n, 
 /* clamp(bmm(pixels, M[:3,:3]) + M[:3,3], 0, 1)  generate.py:405-407, utils/dataloader.py:38-42.
  * src [N,3,h,w]; idx int32[nb] frame of each output (NULL = identity); expo [N,3,4]; out [nb,3,h,w]. */
 int tcl_apply_exposure(const float* src, const int* idx, const float* expo, float* out, int nb, int h, int w, hipStream_t st);
-/* clamp(SH2RGB(features_dc)[unq_inv[frame]], 0, 1)  generate.py:499-501,530-531.  feat [K,3]; inv int32 [N*h*w]. */
-int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, hipStream_t st);
+/* clamp(SH2RGB(features_dc)[unq_inv[frame]], 0, 1)  generate.py:499-501,530-531.  The codebook is stored CHANNEL-PLANAR,
+ * feat [3,K] (= features_dc.t()), so gathers / scatter-adds of neighbouring pixels are contiguous per channel; inv int32 [N*h*w]. */
+int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, size_t K, hipStream_t st);
 /* value[0] = 1 - relaxed_ms_ssim(X, Y, data_range=1, start_level=1)  utils/loss_utils.py:125-211; gradX = d value / dX
  * (NULL to skip).  X, Y: `planes` contiguous h*w planes (= batch*channels). */
 size_t tcl_msssim_workspace_bytes(int planes, int h, int w);
@@ -41,7 +42,7 @@ int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, f
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st);
 /* torch.optim.Adam single-tensor step (generate.py:381,483-487); g is consumed and zeroed. step counts from 1. */
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
-/* RGB2SH(torch_scatter.scatter(pixels, unq_inv, reduce='mean'))  generate.py:477-479.  cnt: K floats scratch. */
+/* RGB2SH(torch_scatter.scatter(pixels, unq_inv, reduce='mean'))  generate.py:477-479 -> feat [3,K] planar.  cnt: K floats scratch. */
 int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, hipStream_t st);
 
 /* Whole-stage drivers: every iteration is enqueued on `st`; no host synchronisation inside.
@@ -56,7 +57,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
                        const int* d_cat, int iters, int iters_per_epoch, int batch, int epochs, float lr_init, float lr_final, float lambda_dssim,
                        float lambda_flow, float* exposure, float* g, float* m, float* v, float* losses, float* aligned_out,
                        void* ws, hipStream_t st);
-/* Generator.unique_tensor_optimization  generate.py:453-533.  feat [K,3] initialised by tcl_scatter_mean_rgb2sh;
+/* Generator.unique_tensor_optimization  generate.py:453-533.  feat/g/m/v [3,K] planar, feat initialised by tcl_scatter_mean_rgb2sh;
  * images_out [N,3,h,w] (may be NULL) receives the final gather. */
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
                           size_t K, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim,

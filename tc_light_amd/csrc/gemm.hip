@@ -219,6 +219,192 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (128x128x32 steps): operands go global -> LDS directly (global_load_lds_dwordx4: the 64 lanes of a wave
+// write 1 KiB contiguous = 16 rows x 64 B), no VGPR staging and no ds_write pass, two 16 KiB stages (one barrier per K-step).
+// Rows are unpadded, so the 16-B chunk index of row r is XOR-swizzled with (r>>2)&3 -- applied to the per-lane SOURCE address
+// and to the ds_read address (cdna guide rule 21) -- which makes the 16-lane ds_read_b128 groups conflict-free.
+// Out-of-range rows / conv taps fetch from a zero page.  ~110 VGPRs and 34.8 KiB LDS -> 4 blocks per CU.
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 4 : 3) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                     const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
+                                                     _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
+                                                     ConvP cp, int tiles_m, int tiles_n) {
+    constexpr int KB = 32;                                  // K per step
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    constexpr int ROWB = KB * 2;                            // bytes per LDS row (64)
+    constexpr int STAGE = (BM + BN) * ROWB;                 // 16 KiB
+    constexpr int A_IT = BM / 16 / 4, B_IT = BN / 16 / 4;   // 1-KiB pieces (16 rows) per wave per operand
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+
+    // DMA lane roles: piece p (16 rows) of an operand; lane -> row rr = lane>>2, LDS chunk c' = lane&3, source chunk c = c' ^ ((rr>>2)&3)
+    const int rr = lane >> 2, csrc = ((lane & 3) ^ ((rr >> 2) & 3)) * 8;          // source offset in halves within the 32-wide K slice
+    const _Float16* zero = (const _Float16*)g_zero_page;
+    long a_off[A_IT]; int a_oy[A_IT], a_ox[A_IT]; bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + (wid * A_IT + i) * 16 + rr;
+        a_ok[i] = m < M;
+        if (!cp.conv) { a_off[i] = (long)m * lda; a_oy[i] = a_ox[i] = 0; }
+        else {
+            int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
+            a_off[i] = (long)b * cp.Hin * cp.Win * cp.Cin; a_oy[i] = oy * cp.stride - cp.pad; a_ox[i] = ox * cp.stride - cp.pad;
+        }
+    }
+    const _Float16* wp[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) { int n = n0 + (wid * B_IT + i) * 16 + rr; wp[i] = n < N ? W + (long)n * ldw + csrc : nullptr; }
+
+#define DMA_ISSUE(KT, BUF)                                                                                                    \
+    {                                                                                                                         \
+        const int k0_ = (KT) * KB;                                                                                            \
+        int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
+        if (cp.conv) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }          \
+        char* sb_ = smem + (BUF) * STAGE;                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                                   \
+            const _Float16* src_ = zero;                                                                                      \
+            if (a_ok[i]) {                                                                                                    \
+                if (!cp.conv) src_ = A + a_off[i] + k0_ + csrc;                                                               \
+                else {                                                                                                        \
+                    int iy_ = a_oy[i] + tdy_, ix_ = a_ox[i] + tdx_;                                                           \
+                    if (iy_ >= 0 && iy_ < cp.Hup && ix_ >= 0 && ix_ < cp.Wup) {                                               \
+                        if (cp.Hup != cp.Hin) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
+                        src_ = A + a_off[i] + ((long)iy_ * cp.Win + ix_) * cp.Cin + c0_ + csrc;                               \
+                    }                                                                                                         \
+                }                                                                                                             \
+            }                                                                                                                 \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
+                                             (__attribute__((address_space(3))) void*)(sb_ + (wid * A_IT + i) * 1024), 16, 0, 0); \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                                                   \
+            const _Float16* src_ = wp[i] ? wp[i] + k0_ : zero;                                                                \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
+                                             (__attribute__((address_space(3))) void*)(sb_ + BM * ROWB + (wid * B_IT + i) * 1024), 16, 0, 0); \
+        }                                                                                                                     \
+    }
+
+    float16v acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = K / KB;
+    const int frow = lane & 31, fh = lane >> 5;
+    // fragment read: row R = tile row (lane&31), logical chunk c = 2*ks + (lane>>5), physical chunk c ^ ((R>>2)&3)
+#define DMA_COMPUTE(BUF)                                                                                                      \
+    {                                                                                                                         \
+        const char* ab = smem + (BUF) * STAGE + (wm * (BM / WM)) * ROWB;                                                      \
+        const char* bb = smem + (BUF) * STAGE + BM * ROWB + (wn * (BN / WN)) * ROWB;                                          \
+        _Pragma("unroll") for (int ks = 0; ks < KB / 16; ++ks) {                                                             \
+            half8 fa[MT], fb[NT];                                                                                             \
+            _Pragma("unroll") for (int a = 0; a < MT; ++a) { int R = a * 32 + frow; fa[a] = *(const half8*)(ab + R * ROWB + (((2 * ks + fh) ^ ((R >> 2) & 3)) << 4)); } \
+            _Pragma("unroll") for (int b = 0; b < NT; ++b) { int R = b * 32 + frow; fb[b] = *(const half8*)(bb + R * ROWB + (((2 * ks + fh) ^ ((R >> 2) & 3)) << 4)); } \
+            _Pragma("unroll") for (int a = 0; a < MT; ++a)                                                                    \
+                _Pragma("unroll") for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0); \
+        }                                                                                                                     \
+    }
+    if constexpr (STAGES == 2) {
+        DMA_ISSUE(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) DMA_ISSUE(kt + 1, cur ^ 1);
+            DMA_COMPUTE(cur);
+            __syncthreads();
+        }
+    } else {
+        // 3-stage ring, prefetch distance 2, ONE raw barrier per step: wait for my own pieces of tile t (counted vmcnt: the newer
+        // tile t+1 stays in flight), barrier (=> every wave's pieces landed AND everyone left tile t-1), refill the stage tile t-1
+        // used with tile t+2, compute tile t.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+        constexpr int PER_TILE = A_IT + B_IT;            // glds instructions per wave per tile
+        DMA_ISSUE(0, 0);
+        if (nk > 1) DMA_ISSUE(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) { const int nb = buf == 0 ? 2 : buf - 1; DMA_ISSUE(kt + 2, nb); }
+            DMA_COMPUTE(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __syncthreads();                                  // all reads done before the epilogue reuses the LDS
+    }
+#undef DMA_COMPUTE
+#undef DMA_ISSUE
+    // epilogue: same LDS-staged vector path as k_gemm (callers guarantee N % 8 == 0 etc. before choosing this kernel)
+    constexpr int CS = BN + 8;
+    _Float16* Cs = (_Float16*)smem;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int nl = wn * (BN / WN) + b * 32 + (lane & 31), n = n0 + nl;
+        const float bv = (bias && n < N) ? (float)bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int ml = wm * (BM / WM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r] + bv;
+                if (act == 1) v = v / (1.f + __expf(-v));
+                Cs[(ml + (r & 3) + 8 * (r >> 2)) * CS + nl] = (_Float16)v;
+            }
+        }
+    }
+    __syncthreads();
+    if (act == 2) {
+        constexpr int CPH = BN / 16;
+#pragma unroll
+        for (int i = 0; i < BM * CPH / 256; ++i) {
+            const int c = tid + 256 * i, row = c / CPH, c8 = (c % CPH) * 8, m = m0 + row, n = (n0 >> 1) + c8;
+            if (m < M && n < (N >> 1)) {
+                half8 va = *(const half8*)(Cs + row * CS + c8), vg = *(const half8*)(Cs + row * CS + BN / 2 + c8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                *(half8*)(C + (long)m * ldc + n) = va;
+            }
+        }
+        return;
+    }
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 256; ++i) {
+        const int c = tid + 256 * i, row = c / CPR, c8 = (c % CPR) * 8, m = m0 + row, n = n0 + c8;
+        if (m < M && n < N) {
+            half8 v = *(const half8*)(Cs + row * CS + c8);
+            if (resid) {
+                half8 rv = *(const half8*)(resid + (long)m * ldr + n);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] + (float)rv[q]);
+            }
+            *(half8*)(C + (long)m * ldc + n) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_gemm_dma(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
+                           int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+    const size_t ops = (size_t)STAGES * (BM + BN) * 64, cs = (size_t)BM * (BN + 8) * 2, lds = ops > cs ? ops : cs;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_dma<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(cdiv(tm, 8) * 8 * tn), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
+                       act, cp, tm, tn);
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
 // split-K second pass: C = act(sum_s part[s] + bias) + resid
 __global__ void k_splitk_finalize(const float* __restrict__ part, int splits, const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                   _Float16* __restrict__ C, int M, int N, int ldc, int ldr, int act) {
@@ -250,8 +436,8 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     // ~2 blocks per CU exist, partials in f32, deterministic second pass.
     const int nk = K / BK;
     int splits = 1;
-    static const int sk_tiles = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 384;
-    static const int sk_target = getenv("TCL_SPLITK_TARGET") ? atoi(getenv("TCL_SPLITK_TARGET")) : 512;
+    static const int sk_tiles = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 700;
+    static const int sk_target = getenv("TCL_SPLITK_TARGET") ? atoi(getenv("TCL_SPLITK_TARGET")) : 1024;
     if (tm * tn < sk_tiles && nk >= 32 && g_ws && act != 2) {     // measured: splitting K < 2048 loses to the extra pass
         splits = min(nk / 8, cdiv(sk_target, tm * tn));
         while (splits > 1 && (size_t)splits * M * N * 4 > g_ws_bytes) --splits;
@@ -269,6 +455,14 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     static const int pf = getenv("TCL_GEMM_PF") ? atoi(getenv("TCL_GEMM_PF")) : 1;       // register prefetch distance (tiles)
     if (act == 2 && (N % 128 != 0 || (N & 15) || (ldc & 7) || resid)) return TCL_EINVAL;  // GEGLU epilogue: 128-wide [a|gate] tiles only
+    static const int dma = getenv("TCL_GEMM_DMA") ? atoi(getenv("TCL_GEMM_DMA")) : 3;   // 0: register-staged, 2/3: LDS-DMA stages
+    const bool vec_ok = (N & 7) == 0 && (ldc & 7) == 0 && (!resid || (ldr & 7) == 0) && (K % 32) == 0;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    static const int sk_tiles_d = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 700;
+    const bool would_split = tiles < sk_tiles_d && K / 64 >= 32 && g_ws && act != 2;
+    if (dma && vec_ok && !would_split && (N % 128 == 0 || N > 512))
+        return dma == 3 ? launch_gemm_dma<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st)
+                        : launch_gemm_dma<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     if (N % 128 == 0 || N > 512) {
         if (pf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         if (pf == 3) return launch_gemm<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);

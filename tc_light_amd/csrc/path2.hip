@@ -4,7 +4,8 @@
 // (the reference synchronises on loss.item() every iteration, generate.py:431,513).
 //
 // Layout: images planar [n,3,H,W] f32 (the reference's NCHW), flows [N,2,H,W], masks [N,1,H,W],
-// unq_inv int32 [N*H*W], codebook [K,3], exposure [N,3,4].
+// unq_inv int32 [N*H*W], codebook channel-planar [3,K] (the reference's features_dc [K,3] transposed: the gather and the
+// scatter-add atomics of 64 neighbouring pixels then touch contiguous addresses per channel), exposure [N,3,4].
 // Reference functions restated (file:line under /root/reference):
 //   warp_flow utils/flow_utils.py:5-16 · relaxed_ms_ssim utils/loss_utils.py:73-211 · TVLoss :324-340
 //   l1_loss :25-26 · exposure_align generate.py:354-451 · unique_tensor_optimization :453-533
@@ -118,25 +119,25 @@ __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restr
 }
 // out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
 __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                                  float* __restrict__ out, int P) {
+                                  float* __restrict__ out, int P, size_t K) {
     const int j = blockIdx.y, f = fidx ? fidx[j] : j;
     const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const float* r = feat + (size_t)iv[p] * 3;
+        const size_t id = (size_t)iv[p];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c * P + p] = fminf(fmaxf(r[c] * SH_C0 + 0.5f, 0.f), 1.f);
+        for (int c = 0; c < 3; ++c) o[c * P + p] = fminf(fmaxf(feat[c * K + id] * SH_C0 + 0.5f, 0.f), 1.f);
     }
 }
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                               const float* __restrict__ gout, float* __restrict__ gfeat, int P) {
+                               const float* __restrict__ gout, float* __restrict__ gfeat, int P, size_t K) {
     const int j = blockIdx.y, f = fidx[j];
     const int* iv = inv + (size_t)f * P; const float* g = gout + (size_t)j * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        size_t id = (size_t)iv[p] * 3;
+        size_t id = (size_t)iv[p];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = feat[id + c] * SH_C0 + 0.5f, gc = g[c * P + p];
-            if (v >= 0.f && v <= 1.f && gc != 0.f) atomicAdd(gfeat + id + c, gc * SH_C0);
+            float v = feat[c * K + id] * SH_C0 + 0.5f, gc = g[c * P + p];
+            if (v >= 0.f && v <= 1.f && gc != 0.f) atomicAdd(gfeat + c * K + id, gc * SH_C0);
         }
     }
 }
@@ -344,7 +345,34 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
             gi[c * P + p] -= gw[c];
             any |= gw[c] != 0.f;
         }
-        if (any) {
+        // scatter of d(loss)/d(warped) into the pre-image gradient.  Fast path: when the 64 lanes of the wave are 64 consecutive
+        // pixels of one row whose taps share the same integer offset, lane l's tap i and lane l-i's tap 0.. land on the same
+        // cell, so the four column taps are merged across lanes with shuffles and ONE atomic per (row, channel) per lane is
+        // issued (12 instead of 48); the last three lanes emit the cells that stick out of the wave.
+        const int lane = threadIdx.x & 63, dx = t.x0 - x, dy = t.y0 - y;
+        const bool uni = __all(p + (63 - lane) < P && y == __builtin_amdgcn_readfirstlane(y) && dx == __builtin_amdgcn_readfirstlane(dx) &&
+                               dy == __builtin_amdgcn_readfirstlane(dy));
+        if (uni) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const int yy = t.y0 + jj;
+                const bool rowok = yy >= 0 && yy < H;        // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gwc = t.wy[jj] * gw[c];
+                    float v0 = gwc * t.wx[0], v1 = gwc * t.wx[1], v2 = gwc * t.wx[2], v3 = gwc * t.wx[3];
+                    float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
+                    float sum = v0 + (lane >= 1 ? u1 : 0.f) + (lane >= 2 ? u2 : 0.f) + (lane >= 3 ? u3 : 0.f);
+                    if (!rowok) continue;
+                    float* row = gp + (size_t)c * P + (size_t)yy * W;
+                    if (t.x0 >= 0 && t.x0 < W && sum != 0.f) atomicAdd(row + t.x0, sum);
+                    if (lane >= 61) {                        // taps that stick out of the wave: emitted by their own lane
+                        if (lane + 1 > 63 && t.x0 + 1 >= 0 && t.x0 + 1 < W) atomicAdd(row + t.x0 + 1, v1);
+                        if (lane + 2 > 63 && t.x0 + 2 >= 0 && t.x0 + 2 < W) atomicAdd(row + t.x0 + 2, v2);
+                        if (lane + 3 > 63 && t.x0 + 3 >= 0 && t.x0 + 3 < W) atomicAdd(row + t.x0 + 3, v3);
+                    }
+                }
+            }
+        } else if (any) {
             for (int jj = 0; jj < 4; ++jj) {
                 int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
                 for (int i = 0; i < 4; ++i) {
@@ -378,18 +406,18 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     }
 }
 __global__ void k_scatter_accum(const float* __restrict__ img, const int* __restrict__ inv, float* __restrict__ sum,
-                                float* __restrict__ cnt, int P) {
+                                float* __restrict__ cnt, int P, size_t K) {
     const int f = blockIdx.y;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         size_t id = inv[(size_t)f * P + p];
         const float* s = img + (size_t)f * 3 * P;
-        atomicAdd(sum + id * 3, s[p]); atomicAdd(sum + id * 3 + 1, s[P + p]); atomicAdd(sum + id * 3 + 2, s[2 * P + p]);
+        atomicAdd(sum + id, s[p]); atomicAdd(sum + K + id, s[P + p]); atomicAdd(sum + 2 * K + id, s[2 * P + p]);
         atomicAdd(cnt + id, 1.f);
     }
 }
 __global__ void k_scatter_final(float* __restrict__ feat, const float* __restrict__ cnt, size_t K) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < K * 3; i += (size_t)gridDim.x * blockDim.x)
-        feat[i] = (feat[i] / fmaxf(cnt[i / 3], 1.f) - 0.5f) / SH_C0;  // mean then RGB2SH (generate.py:478-479)
+        feat[i] = (feat[i] / fmaxf(cnt[i % K], 1.f) - 0.5f) / SH_C0;  // mean then RGB2SH (generate.py:478-479); planar [3,K]
 }
 
 // ================================================================= host side (C ABI)
@@ -414,9 +442,9 @@ int tcl_apply_exposure(const float* src, const int* idx, const float* expo, floa
     hipLaunchKernelGGL(k_apply_exposure, pgrid(h * w, nb), dim3(256), 0, st, src, idx, expo, out, h * w);
     TCL_LAUNCH_RET();
 }
-int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, hipStream_t st) {
+int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, size_t K, hipStream_t st) {
     TCL_CHECK_ARG(feat && inv && out && nb > 0);
-    hipLaunchKernelGGL(k_gather_codebook, pgrid(h * w, nb), dim3(256), 0, st, feat, inv, fidx, out, h * w);
+    hipLaunchKernelGGL(k_gather_codebook, pgrid(h * w, nb), dim3(256), 0, st, feat, inv, fidx, out, h * w, K);
     TCL_LAUNCH_RET();
 }
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
@@ -428,7 +456,7 @@ int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, fl
 int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, hipStream_t st) {
     TCL_CHECK_ARG(img && inv && feat && cnt && K > 0);
     if (hipMemsetAsync(feat, 0, K * 12, st) != hipSuccess || hipMemsetAsync(cnt, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
-    hipLaunchKernelGGL(k_scatter_accum, pgrid(h * w, n), dim3(256), 0, st, img, inv, feat, cnt, h * w);
+    hipLaunchKernelGGL(k_scatter_accum, pgrid(h * w, n), dim3(256), 0, st, img, inv, feat, cnt, h * w, K);
     hipLaunchKernelGGL(k_scatter_final, dim3(stream_grid((long)K * 3, 256, 4)), dim3(256), 0, st, feat, cnt, K);
     TCL_LAUNCH_RET();
 }
@@ -564,7 +592,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
     TCL_LAUNCH_RET();
 }
 
-// Stage 2 (generate.py:453-533).  feat/g/m/v: [K,3] device (feat initialised by tcl_scatter_mean_rgb2sh, others 0).
+// Stage 2 (generate.py:453-533).  feat/g/m/v: channel-planar [3,K] device (feat initialised by tcl_scatter_mean_rgb2sh, others 0).
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
                           size_t K, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
                           float lambda_tv, float* feat, float* g, float* m, float* v, float* losses, float* images_out, void* ws,
@@ -581,7 +609,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
         S.cidx = const_cast<int*>(d_cat) + (size_t)it * 2 * batch;
-        hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P);
+        hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
         // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
         int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st);
         if (rc) return rc;
@@ -591,12 +619,12 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
         float inv_cnt = nvalid ? 1.f / ((float)nvalid * 3 * P) : 0.f;
         hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
-        hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P);
+        hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P, K);
         hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, losses + it);
         rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
         if (rc) return rc;
     }
-    if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P);
+    if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P, K);
     TCL_LAUNCH_RET();
 }
 

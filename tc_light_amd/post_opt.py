@@ -174,7 +174,7 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
     if k is None:
         k = int(inv.max()) + 1
     sched, d_cat = _pack_schedule(batches, batch_size, dev)
-    feat = torch.empty(k, 3, device=dev)
+    feat = torch.empty(3, k, device=dev)        # channel-planar codebook (features_dc.t())
     cnt = torch.empty(k, device=dev)
     lib().tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, stream())
     del cnt
@@ -185,4 +185,4 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
     lib().tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, sched.ctypes.data, d_cat,
                                 len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
                                 losses, out, ws, stream())
-    return out, feat, losses[:len(sched)]
+    return out, feat.t(), losses[:len(sched)]      # features_dc in the reference's [K,3] orientation (a view)

@@ -122,6 +122,19 @@ def unet_flops_unmerged(B, h, w, L):
     return fl + 2.0 * B * h * w * 9 * 320 * 4
 
 
+def measured_traffic():
+    """HBM-side bytes per k_flash<40,...> launch from the committed PMC passes (tools/collect_profiles.sh -> profiles/*_flash40_traffic.json).
+    PMC counters cannot be read from inside the timed process, so the newest committed measurement of this same command is reported."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_flash40_traffic.json")))
+    if not fs:
+        return None
+    try:
+        return json.load(open(fs[-1]))["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,7 +224,7 @@ def main():
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
             "roofline": {"bound": "mfma", "kernel": "k_flash<48,64> (head_dim 40 attention, self + text)", "achieved": ach,
                          "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
-                         "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": None,
+                         "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": measured_traffic(),
                          "unet_algorithmic_tflop_per_pass": unet.flops / 1e12},
         }
         if world == 1 and not a.no_cpu_baseline:

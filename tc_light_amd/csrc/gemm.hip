@@ -18,6 +18,7 @@
 #include "common.h"
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
+#include "gemm_conv.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -26,13 +27,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define BK 64
 #define LDS_STRIDE 72  // halves
 
-struct ConvP {
-    int conv;            // 0: dense A[M][lda]; 1: implicit 3x3
-    int Hin, Win, Cin;   // stored input (before optional upsample)
-    int Hup, Wup;        // logical input size seen by the conv (== Hin,Win unless nearest-upsampled)
-    int Hout, Wout, stride, pad;
-    float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
-};
 
 template <int BM, int BN, int WM, int WN, int PF>
 __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
@@ -228,7 +222,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
 
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 4 : 3) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+__global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128 ? 2 : (STAGES == 2 ? 4 : 3)) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                      _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
                                                      ConvP cp, int tiles_m, int tiles_n) {
@@ -460,9 +454,19 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
     static const int sk_tiles_d = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 700;
     const bool would_split = tiles < sk_tiles_d && K / 64 >= 32 && g_ws && act != 2;
-    if (dma && vec_ok && !would_split && (N % 128 == 0 || N > 512))
+    static const int big = getenv("TCL_GEMM_BIG") ? atoi(getenv("TCL_GEMM_BIG")) : 0;   // experimental larger block tiles
+    static const int g8 = getenv("TCL_GEMM8") ? atoi(getenv("TCL_GEMM8")) : 0;           // 8-wave ping-pong kernel config (gemm8.hip)
+    if (g8 && vec_ok && act != 2 && M >= 4096 && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0)) {
+        if ((g8 == 1 || g8 == 2) && N % 320 == 0) return gemm8_dispatch(g8, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        if ((g8 == 3 || g8 == 4) && N % 256 == 0) return gemm8_dispatch(g8, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
+    if (dma && vec_ok && !would_split && (N % 128 == 0 || N > 512)) {
+        if (big == 1 && M >= 4096) return launch_gemm_dma<256, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        if (big == 2 && M >= 4096 && act != 2) return launch_gemm_dma<128, 256, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        if (big == 3 && M >= 4096 && act != 2) return launch_gemm_dma<256, 256, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         return dma == 3 ? launch_gemm_dma<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st)
                         : launch_gemm_dma<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
     if (N % 128 == 0 || N > 512) {
         if (pf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         if (pf == 3) return launch_gemm<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);

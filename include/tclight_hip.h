@@ -76,6 +76,15 @@ int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* res
 /* Register caller-owned device scratch for split-K partial sums (used by tcl_gemm_f16 / tcl_conv3x3_f16 when the tile grid
  * would leave most CUs idle).  NULL disables split-K.  All calls that use it must be issued on one stream. */
 int tcl_set_workspace(void* ws, size_t bytes);
+/* Tuning / test hook: force the kernel configuration (cfg ids in csrc/gemm.hip; 0 = automatic choice) and the number of K
+ * splits (0/1 = none) for every following tcl_gemm_f16 / tcl_conv3x3_f16 call; calls the forced configuration cannot serve
+ * return TCL_EINVAL.  Process-global, not thread-safe. */
+int tcl_gemm_tune(int cfg, int splits);
+/* Automatic configuration choice (default on): the first call with a new problem shape times the candidate tile
+ * configurations on the caller's stream (synchronising it once) and caches the winner for the life of the process; results are
+ * bit-identical whichever candidate wins (the K-split count is a fixed function of the shape).  0 = static heuristic only and
+ * drops the cache. */
+int tcl_gemm_autotune(int enable);
 /* 3x3 Conv2d as implicit GEMM on NHWC: X [B,Hin,Win,Cin], W [Cout, 9*Cin] (tap-major: (ky*3+kx)*Cin + c), Y [B,Hout,Wout,Cout].
  * pad=1: padding 1 (UNet ResnetBlock2D / Downsample2D stride 2); pad=0 with stride 2: the VAE encoder's (0,1,0,1) padding.
  * Hup/Wup > 0: the input is first nearest-upsampled to Hup x Wup (Upsample2D with explicit output size), fused in the gather. */

@@ -23,7 +23,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define KV_TILE 64
-#define V_STRIDE 68   // halves: 34 dwords -> the 32 rows of a ds_read_b64 group hit 32 distinct even bank pairs
+#define V_STRIDE 72   // halves: 144 B = 9 x 16 B (odd) -> the 16-lane groups of a ds_read_b128 are conflict-free
 
 __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
                             _Float16* __restrict__ dst, int Tp, int DP, long total_chunks) {
@@ -42,7 +42,9 @@ __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int 
         *(half8*)(dst + i * 8) = v;
     }
 }
-// Vt[b][h][i][t] = V[b][t][h*d + i]; one block per (64 tokens, b*h)
+// Vt[b][h][i][p(t)] = V[b][t][h*d + i]; one block per (64 tokens, b*h).  Within every group of 16 keys the two middle blocks of 4
+// are swapped (p swaps bits 2 and 3 of t): the S^T accumulator of the flash kernel leaves lane half hl with keys {4hl..4hl+3,
+// 8+4hl..8+4hl+3} of a group, and with this order those 8 V^T values are one contiguous 16-B LDS read (8*hl .. 8*hl+7).
 __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
                                                  _Float16* __restrict__ vt, int Tp, int DPV) {
     extern __shared__ _Float16 tile[];   // [64][DPV+2]
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
         int dd = i / 64, r = i % 64;
         _Float16 val = tile[r * st + dd];
         if (dd == d && DPV > d) val = (t0 + r < T) ? (_Float16)1.f : (_Float16)0.f;   // ones row: the PV MFMA also yields the softmax row sums
-        vt[((long)bh * DPV + dd) * Tp + t0 + r] = val;
+        const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        vt[((long)bh * DPV + dd) * Tp + t0 + pr] = val;
     }
 }
 
@@ -115,11 +118,10 @@ __device__ __forceinline__ void flash_tile(const _Float16* __restrict__ kt, cons
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 4 * hl;
+            const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 8 * hl;
 #pragma unroll
             for (int t = 0; t < NDT; ++t) {
-                half4 lo = *(const half4*)(vr + t * 32 * V_STRIDE), hi = *(const half4*)(vr + t * 32 * V_STRIDE + 8);
-                half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                half8 vf = *(const half8*)(vr + t * 32 * V_STRIDE);
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][ss], o[t], 0, 0, 0);
             }
         }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(NW * 64, (DP <= 48 && NW == 4) ? 3 : 2) void k_flas
 #define FLASH_SSTORE(BUF, RK, RV)                                                                                             \
     {                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= KCH || c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(u32x4*)(Ks + ((BUF) * KV_TILE + r) * KS + c8) = RK[i]; } } \
-        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= VCH || c < VCH) { u32x2* p_ = (u32x2*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8); p_[0] = RV[i].xy; p_[1] = RV[i].zw; } } \
+        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= VCH || c < VCH) { *(u32x4*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8) = RV[i]; } } \
     }
 #define FLASH_TILE(BUF, IT) flash_tile<DP, DPV, LROW>(Ks + (BUF) * KV_TILE * KS, Vs + (BUF) * DPV * V_STRIDE, qf, o, m, lsum, ql, hl, (IT) * KV_TILE, Tk, (IT) >= nfull)
 

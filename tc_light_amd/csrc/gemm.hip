@@ -18,6 +18,7 @@
 #include "common.h"
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
+#include <unordered_map>
 #include "gemm_conv.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -222,10 +223,10 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
 
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128 ? 2 : (STAGES == 2 ? 4 : 3)) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+__global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128 ? 2 : BM * BN < 128 * 128 ? 4 : (STAGES == 2 ? 4 : 3)) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                      _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
-                                                     ConvP cp, int tiles_m, int tiles_n) {
+                                                     ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part) {
     constexpr int KB = 32;                                  // K per step
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int ROWB = KB * 2;                            // bytes per LDS row (64)
@@ -233,7 +234,9 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
     constexpr int A_IT = BM / 16 / 4, B_IT = BN / 16 / 4;   // 1-KiB pieces (16 rows) per wave per operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tgrid = ((tiles_m + 7) >> 3) * 8 * tiles_n;        // blocks per K-split
+    const int split = blockIdx.x / tgrid;
+    const int bid = blockIdx.x - split * tgrid, xcd = bid & 7, j = bid >> 3;
     const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
     if (tm >= tiles_m) return;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
 
 #define DMA_ISSUE(KT, BUF)                                                                                                    \
     {                                                                                                                         \
-        const int k0_ = (KT) * KB;                                                                                            \
+        const int k0_ = (kbeg + (KT)) * KB;                                                                                   \
         int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
         if (cp.conv) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }          \
         char* sb_ = smem + (BUF) * STAGE;                                                                                     \
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = K / KB;
+    const int kbeg = split * nk_per, nk = min(K / KB, kbeg + nk_per) - kbeg;      // this block's K steps: [kbeg, kbeg + nk)
     const int frow = lane & 31, fh = lane >> 5;
     // fragment read: row R = tile row (lane&31), logical chunk c = 2*ks + (lane>>5), physical chunk c ^ ((R>>2)&3)
 #define DMA_COMPUTE(BUF)                                                                                                      \
@@ -338,6 +341,23 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
     }
 #undef DMA_COMPUTE
 #undef DMA_ISSUE
+    if (part) {     // split-K partial sums (f32): lane holds column n = lane&31 and rows (r&3)+8*(r>>2)+4*(lane>>5) of each 32x32 tile
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + wn * (BN / WN) + b * 32 + (lane & 31);
+            if (n >= N) continue;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int mb = m0 + wm * (BM / WM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < M) part[((long)split * M + m) * N + n] = acc[a][b][r];
+                }
+            }
+        }
+        return;
+    }
     // epilogue: same LDS-staged vector path as k_gemm (callers guarantee N % 8 == 0 etc. before choosing this kernel)
     constexpr int CS = BN + 8;
     _Float16* Cs = (_Float16*)smem;
@@ -387,15 +407,28 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
     }
 }
 
+// caller-owned scratch for split-K partials (tcl_set_workspace); all GEMMs using it must be issued on one stream
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+__global__ void k_splitk_finalize(const float* __restrict__ part, int splits, const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
+                                  _Float16* __restrict__ C, int M, int N, int ldc, int ldr, int act);
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 static int launch_gemm_dma(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
-                           int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+                           int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st, int splits = 1) {
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN), nk = K / 32;
     const size_t ops = (size_t)STAGES * (BM + BN) * 64, cs = (size_t)BM * (BN + 8) * 2, lds = ops > cs ? ops : cs;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_dma<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(cdiv(tm, 8) * 8 * tn), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
-                       act, cp, tm, tn);
+    if (splits > nk / 4) splits = nk / 4 > 0 ? nk / 4 : 1;
+    while (splits > 1 && (!g_ws || (size_t)splits * M * N * 4 > g_ws_bytes)) --splits;
+    if (act == 2) splits = 1;
+    const int nk_per = cdiv(nk, splits);
+    splits = cdiv(nk, nk_per);
+    float* part = splits > 1 ? g_ws : nullptr;
+    hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(cdiv(tm, 8) * 8 * tn * splits), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
+                       act, cp, tm, tn, nk_per, part);
+    if (part) hipLaunchKernelGGL(k_splitk_finalize, dim3(stream_grid((long)M * N, 256, 4)), dim3(256), 0, st, part, splits, bias, resid, C, M, N, ldc, ldr, act);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -413,10 +446,6 @@ __global__ void k_splitk_finalize(const float* __restrict__ part, int splits, co
     }
 }
 
-// caller-owned scratch for split-K partials (tcl_set_workspace); all GEMMs using it must be issued on one stream
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-
 template <int BM, int BN, int WM, int WN, int PF>
 static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
                        int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
@@ -430,8 +459,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     // ~2 blocks per CU exist, partials in f32, deterministic second pass.
     const int nk = K / BK;
     int splits = 1;
-    static const int sk_tiles = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 700;
-    static const int sk_target = getenv("TCL_SPLITK_TARGET") ? atoi(getenv("TCL_SPLITK_TARGET")) : 1024;
+    const int sk_tiles = 700, sk_target = 1024;
     if (tm * tn < sk_tiles && nk >= 32 && g_ws && act != 2) {     // measured: splitting K < 2048 loses to the extra pass
         splits = min(nk / 8, cdiv(sk_target, tm * tn));
         while (splits > 1 && (size_t)splits * M * N * 4 > g_ws_bytes) --splits;
@@ -445,41 +473,129 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
+// ---- configuration choice.  cfg ids (also the tcl_gemm_tune ids):
+//   1 dma 128x128   2 dma 64x128   3 dma 128x64   4 dma 64x64   11 dma 256x128      (k_gemm_dma, 3 stages, optional split-K)
+//   5 g8 256x320    6 g8 128x320   7 g8 256x256   8 g8 128x256                      (gemm8.hip, 8-wave ping-pong)
+//   9 reg 128x128   10 reg 128x64                                                    (k_gemm, register-staged; any N / ld)
+static int g_tune_cfg = 0, g_tune_splits = 0;
+
+static int run_cfg(int cfg, int splits, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
+                   int K, int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+    switch (cfg) {
+        case 1: return launch_gemm_dma<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st, splits);
+        case 2: return launch_gemm_dma<64, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st, splits);
+        case 3: return launch_gemm_dma<128, 64, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st, splits);
+        case 4: return launch_gemm_dma<64, 64, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st, splits);
+        case 11: return launch_gemm_dma<256, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st, splits);
+        case 5: case 6: case 7: case 8: return gemm8_dispatch(cfg - 4, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        case 9: return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        case 10: return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
+    return TCL_EINVAL;
+}
+
+static bool cfg_ok(int cfg, int M, int N, int K, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
+    const bool vec_ok = (N & 7) == 0 && (ldc & 7) == 0 && (!has_resid || (ldr & 7) == 0) && (K % 32) == 0;
+    if (cfg == 9 || cfg == 10) return act != 2 || cfg == 9;
+    if (!vec_ok) return false;
+    if (cfg >= 5 && cfg <= 8) return act != 2 && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0);
+    if (act == 2) return cfg == 1 || cfg == 2 || cfg == 11;            // GEGLU epilogue: 128-wide [value | gate] tiles
+    return true;
+}
+
+// ---- automatic choice: a per-process cache keyed by the problem shape, filled on first use by timing the valid candidates on the
+// caller's stream (hipEvents; the tuning call synchronises the stream, later calls are a hash lookup).  Numerics do not depend
+// on the outcome: every tile configuration accumulates each output element over k in the same order (16-wide MFMA blocks in
+// sequence, f32), and the number of K splits -- the only thing that changes the summation order -- is a fixed function of
+// the shape (split_rule), identical for all candidates.
+struct TuneKey {
+    int conv, M, N, K, act, hasr, Hin, Win, Cin, stride, Hup;
+    bool operator==(const TuneKey& o) const {
+        return conv == o.conv && M == o.M && N == o.N && K == o.K && act == o.act && hasr == o.hasr && Hin == o.Hin && Win == o.Win && Cin == o.Cin &&
+               stride == o.stride && Hup == o.Hup;
+    }
+};
+struct TuneKeyHash {
+    size_t operator()(const TuneKey& k) const {
+        size_t h = 1469598103934665603ull;
+        const int v[11] = {k.conv, k.M, k.N, k.K, k.act, k.hasr, k.Hin, k.Win, k.Cin, k.stride, k.Hup};
+        for (int x : v) { h ^= (size_t)(unsigned)x; h *= 1099511628211ull; }
+        return h;
+    }
+};
+static std::unordered_map<TuneKey, int, TuneKeyHash> g_tune_cache;
+static int g_autotune = 1;
+
+static int split_rule(int M, int N, int K, int act) {
+    const int t128 = cdiv(M, 128) * cdiv(N, 128), nk = K / 32;
+    if (act == 2 || !g_ws || t128 >= 384 || nk < 64) return 1;
+    int s = (640 + t128 / 2) / t128;
+    if (s > 8) s = 8;
+    if (s > nk / 16) s = nk / 16;
+    while (s > 1 && (size_t)s * M * N * 4 > g_ws_bytes) --s;
+    return s < 1 ? 1 : s;
+}
+
+static int heuristic_cfg(int M, int N, int K, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
+    if (cfg_ok(1, M, N, K, ldc, ldr, has_resid, act, cp)) return (N % 128 == 0 || N > 192) ? 1 : 3;
+    return (N % 128 == 0 || N > 512) ? 9 : 10;
+}
+
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    static const int pf = getenv("TCL_GEMM_PF") ? atoi(getenv("TCL_GEMM_PF")) : 1;       // register prefetch distance (tiles)
     if (act == 2 && (N % 128 != 0 || (N & 15) || (ldc & 7) || resid)) return TCL_EINVAL;  // GEGLU epilogue: 128-wide [a|gate] tiles only
-    static const int dma = getenv("TCL_GEMM_DMA") ? atoi(getenv("TCL_GEMM_DMA")) : 3;   // 0: register-staged, 2/3: LDS-DMA stages
-    const bool vec_ok = (N & 7) == 0 && (ldc & 7) == 0 && (!resid || (ldr & 7) == 0) && (K % 32) == 0;
-    const int tiles = cdiv(M, 128) * cdiv(N, 128);
-    static const int sk_tiles_d = getenv("TCL_SPLITK_TILES") ? atoi(getenv("TCL_SPLITK_TILES")) : 700;
-    const bool would_split = tiles < sk_tiles_d && K / 64 >= 32 && g_ws && act != 2;
-    static const int big = getenv("TCL_GEMM_BIG") ? atoi(getenv("TCL_GEMM_BIG")) : 0;   // experimental larger block tiles
-    static const int g8 = getenv("TCL_GEMM8") ? atoi(getenv("TCL_GEMM8")) : 0;           // 8-wave ping-pong kernel config (gemm8.hip)
-    if (g8 && vec_ok && act != 2 && M >= 4096 && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0)) {
-        if ((g8 == 1 || g8 == 2) && N % 320 == 0) return gemm8_dispatch(g8, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        if ((g8 == 3 || g8 == 4) && N % 256 == 0) return gemm8_dispatch(g8, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    if (g_tune_cfg) {
+        if (!cfg_ok(g_tune_cfg, M, N, K, ldc, ldr, resid != nullptr, act, cp)) return TCL_EINVAL;
+        return run_cfg(g_tune_cfg, g_tune_splits > 0 ? g_tune_splits : 1, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     }
-    if (dma && vec_ok && !would_split && (N % 128 == 0 || N > 512)) {
-        if (big == 1 && M >= 4096) return launch_gemm_dma<256, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        if (big == 2 && M >= 4096 && act != 2) return launch_gemm_dma<128, 256, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        if (big == 3 && M >= 4096 && act != 2) return launch_gemm_dma<256, 256, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        return dma == 3 ? launch_gemm_dma<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st)
-                        : launch_gemm_dma<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    const bool hasr = resid != nullptr;
+    const int splits = split_rule(M, N, K, act);
+    const int fallback = heuristic_cfg(M, N, K, ldc, ldr, hasr, act, cp);
+    if (fallback >= 9) return run_cfg(fallback, 1, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);   // odd N / ld: register-staged kernel
+    // re-running the call must be idempotent: no tuning when the output overlaps an input
+    const char* c0 = (const char*)C; const char* c1 = c0 + ((size_t)(M - 1) * ldc + N) * 2;
+    auto overlaps = [&](const void* p, size_t bytes) { return p && (const char*)p < c1 && (const char*)p + bytes > c0; };
+    const size_t a_bytes = cp.conv ? (size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 : ((size_t)(M - 1) * lda + K) * 2;
+    if (!g_autotune || overlaps(A, a_bytes) || (resid && overlaps(resid, ((size_t)(M - 1) * ldr + N) * 2)))
+        return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    const TuneKey key = {cp.conv, M, N, K, act, (int)hasr, cp.Hin, cp.Win, cp.Cin, cp.stride, cp.Hup};
+    auto it = g_tune_cache.find(key);
+    if (it != g_tune_cache.end()) return run_cfg(it->second, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs
+    int cand[9], nc = 0;
+    const int t128 = cdiv(M, 128) * cdiv(N, 128);
+    cand[nc++] = 1;
+    if (t128 < 4096) { cand[nc++] = 2; if (act != 2) cand[nc++] = 3; }
+    if (t128 < 1024 && act != 2) cand[nc++] = 4;
+    if (t128 >= 256) cand[nc++] = 11;
+    if (splits == 1 && K >= 512) {
+        if (N % 320 == 0 && N % 256 != 0) { if (cdiv(M, 256) * (N / 320) >= 96) cand[nc++] = 5; if (cdiv(M, 128) * (N / 320) >= 96) cand[nc++] = 6; }
+        if (N % 256 == 0) { if (cdiv(M, 256) * (N / 256) >= 96) cand[nc++] = 7; if (cdiv(M, 128) * (N / 256) >= 96) cand[nc++] = 8; }
     }
-    if (N % 128 == 0 || N > 512) {
-        if (pf == 2) return launch_gemm<128, 128, 2, 2, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        if (pf == 3) return launch_gemm<128, 128, 2, 2, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int best = fallback; float best_ms = 1e30f;
+    for (int i = 0; i < nc; ++i) {
+        if (!cfg_ok(cand[i], M, N, K, ldc, ldr, hasr, act, cp)) continue;
+        if (run_cfg(cand[i], splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st) != TCL_OK) continue;     // warm-up
+        hipEventRecord(e0, st);
+        for (int r = 0; r < 3; ++r) run_cfg(cand[i], splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = cand[i]; }
     }
-    if (pf == 2) return launch_gemm<128, 64, 4, 1, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-    if (pf == 3) return launch_gemm<128, 64, 4, 1, 3>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-    return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    g_tune_cache[key] = best;
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;      // the timed runs already produced C
 }
 
 extern "C" {
 
 int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = ws ? bytes : 0; return TCL_OK; }
+int tcl_gemm_tune(int cfg, int splits) { g_tune_cfg = cfg; g_tune_splits = splits; return TCL_OK; }
+int tcl_gemm_autotune(int enable) { g_autotune = enable; if (!enable) g_tune_cache.clear(); return TCL_OK; }
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {

@@ -261,3 +261,59 @@ def test_gemm_fused_geglu(L):
     L.tcl_gemm_f16(A, _geglu_rows(W).contiguous(), _geglu_rows(b).contiguous(), 0, out, M, 8 * C, C, C, C, 4 * C, 8 * C, 2, st())
     f = A.float() @ W.float().t() + b.float()
     assert rel(out, f[:, :4 * C] * F.gelu(f[:, 4 * C:])) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [("g", 5520, 1280, 1280), ("g", 21600, 640, 640), ("g", 1472, 1280, 2560), ("c", 8, 23, 30, 640, 640),
+                                   ("c", 8, 4, 12, 1280, 1280)])
+def test_gemm_configs_bit_identical(L, shape):
+    """Every tile configuration (LDS-DMA 128x128 / 64x128 / 128x64 / 64x64 / 256x128 and the 8-wave 256x320 / 128x320 / 256x256 /
+    128x256 kernels) accumulates each output in the same k order, so with equal K splits the results are bit-identical -- the
+    property the automatic configuration choice relies on -- and the automatic choice itself matches them."""
+    ws = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
+    L.tcl_set_workspace(ws, ws.numel())
+    g = torch.Generator(device="cuda").manual_seed(3)
+    if shape[0] == "g":
+        _, M, N, K = shape
+        A = torch.randn(M, K, device="cuda", generator=g).to(H)
+        W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(H)
+        b, R = torch.randn(N, device="cuda", generator=g).to(H), torch.randn(M, N, device="cuda", generator=g).to(H)
+
+        def run():
+            C = torch.empty(M, N, device="cuda", dtype=H)
+            L.tcl_gemm_f16(A, W, b, R, C, M, N, K, K, K, N, N, 0, st())
+            return C
+        ref = A.float() @ W.float().t() + b.float() + R.float()
+    else:
+        _, B, Hh, Ww, Ci, Co = shape
+        x = torch.randn(B, Hh, Ww, Ci, device="cuda", generator=g).to(H)
+        w = (torch.randn(Co, 9 * Ci, device="cuda", generator=g) / (9 * Ci) ** 0.5).to(H)
+        b = torch.randn(Co, device="cuda", generator=g).to(H)
+
+        def run():
+            y = torch.empty(B, Hh, Ww, Co, device="cuda", dtype=H)
+            L.tcl_conv3x3_f16(x, w, b, 0, y, B, Hh, Ww, Ci, Co, 1, 1, 0, 0, 0, st())
+            return y
+        ref = F.conv2d(x.permute(0, 3, 1, 2).float(), w.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    try:
+        for splits in (1, 4):
+            outs = {}
+            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8):
+                if splits > 1 and cfg in (5, 6, 7, 8):
+                    continue
+                L.tcl_gemm_tune(cfg, splits)
+                try:
+                    outs[cfg] = run()
+                except RuntimeError:          # configuration not applicable to this shape
+                    continue
+            assert len(outs) >= 4
+            first = next(iter(outs.values()))
+            assert rel(first, ref) < 2e-3
+            for cfg, o in outs.items():
+                assert torch.equal(o, first), f"cfg {cfg} splits {splits} differs"
+        L.tcl_gemm_tune(0, 0)
+        auto1, auto2 = run(), run()            # first call tunes, second hits the cache
+        assert torch.equal(auto1, auto2) and rel(auto1, ref) < 2e-3
+    finally:
+        L.tcl_gemm_tune(0, 0)
+        L.tcl_set_workspace(0, 0)
+    torch.cuda.synchronize()

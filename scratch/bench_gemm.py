@@ -25,6 +25,6 @@ for B,Hh,Ww,Ci,Co in [(8,90,120,320,320),(8,45,60,640,640),(8,23,30,1280,1280),(
 print("groupnorm")
 for B,HW,C in [(8,10800,320),(8,2700,640),(8,10800,960)]:
     x=torch.randn(B,HW,C,device='cuda').to(H); g=torch.ones(C,device='cuda',dtype=H); y=torch.empty_like(x)
-    ws=torch.empty(L.tcl_groupnorm_workspace_bytes(B,C),dtype=torch.uint8,device='cuda')
+    ws=torch.zeros(L.tcl_groupnorm_workspace_bytes(B,C),dtype=torch.uint8,device='cuda')
     ms=timeit(lambda: L.tcl_groupnorm_f16(x,C,0,0,g,g,y,B,HW,32,1e-5,1,ws,st()))
     print(f"GN {B}x{HW}x{C}: {ms*1e3:8.1f} us  {x.numel()*2*3/ms/1e6:6.0f} GB/s")

@@ -6,6 +6,7 @@
 // scheduler.step generate.py:235; encode/decode_latents utils/VidToMe/generate_utils.py:140-172.
 #include "common.h"
 #include "../../include/tclight_hip.h"
+#include <unordered_map>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
@@ -48,33 +49,32 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
     __syncthreads();
     if (threadIdx.x < G) { atomicAdd(ws + ((long)b * G + threadIdx.x) * 2, gs[threadIdx.x]); atomicAdd(ws + ((long)b * G + threadIdx.x) * 2 + 1, gq[threadIdx.x]); }
 }
-// pass 2a: per-(batch, channel) scale/shift
-__global__ void k_gn_coef(const float* __restrict__ ws, const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, int C,
-                          int G, float n, float eps, float* __restrict__ coef) {
-    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const int g = c / (C / G);
-    float mean = ws[((long)b * G + g) * 2] / n, var = ws[((long)b * G + g) * 2 + 1] / n - mean * mean;
-    float rstd = rsqrtf(fmaxf(var, 0.f) + eps), ga = (float)gamma[c];
-    coef[((long)b * C + c) * 2] = rstd * ga;
-    coef[((long)b * C + c) * 2 + 1] = (float)beta[c] - mean * rstd * ga;
-}
-// pass 2b: y = act(x*scale + shift), also materialises the channel concat
+// pass 2: y = act((x - mean) * rstd * gamma + beta) with the per-(batch, group) statistics folded in per 8-channel chunk (a chunk
+// touches at most two groups); also materialises the channel concat.  Block (0, b) clears the OTHER statistics slot of this
+// batch entry, which the next GroupNorm call on the same workspace accumulates into (no memset launch between calls).
 __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
-                                                  const float* __restrict__ coef, _Float16* __restrict__ y, int HW, int silu) {
-    const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8;
+                                                  const float* __restrict__ sums, float* __restrict__ sums_next, const _Float16* __restrict__ gamma,
+                                                  const _Float16* __restrict__ beta, float inv_n, float eps, int G, _Float16* __restrict__ y, int HW,
+                                                  int silu) {
+    const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8, cpg = C / G;
+    if (blockIdx.x == 0 && threadIdx.x < 2 * G) sums_next[(long)b * G * 2 + threadIdx.x] = 0.f;
     const long total = (long)HW * nchunk;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         long row = i / nchunk; int ch = (int)(i % nchunk) * 8;
         const _Float16* p = ch < C1 ? x1 + ((long)b * HW + row) * C1 + ch : x2 + ((long)b * HW + row) * C2 + (ch - C1);
         h8 v = *(const h8*)p, o;
-        const float4* cf = (const float4*)(coef + ((long)b * C + ch) * 2);
+        const h8 ga = *(const h8*)(gamma + ch), be = *(const h8*)(beta + ch);
+        const int g0 = ch / cpg, g1 = (ch + 7) / cpg, split = (g0 + 1) * cpg - ch;      // channels j >= split belong to g1
+        const float2 s0 = *(const float2*)(sums + ((long)b * G + g0) * 2), s1 = *(const float2*)(sums + ((long)b * G + g1) * 2);
+        const float m0 = s0.x * inv_n, m1 = s1.x * inv_n;
+        const float r0 = rsqrtf(fmaxf(s0.y * inv_n - m0 * m0, 0.f) + eps), r1 = rsqrtf(fmaxf(s1.y * inv_n - m1 * m1, 0.f) + eps);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 c4 = cf[j];
-            float a = (float)v[2 * j] * c4.x + c4.y, bb = (float)v[2 * j + 1] * c4.z + c4.w;
-            if (silu) { a = a / (1.f + __expf(-a)); bb = bb / (1.f + __expf(-bb)); }
-            o[2 * j] = (_Float16)a; o[2 * j + 1] = (_Float16)bb;
+        for (int j = 0; j < 8; ++j) {
+            const float mean = j < split ? m0 : m1, rstd = j < split ? r0 : r1;
+            const float sc = rstd * (float)ga[j], sh = (float)be[j] - mean * sc;
+            float a = (float)v[j] * sc + sh;
+            if (silu) a = a / (1.f + __expf(-a));
+            o[j] = (_Float16)a;
         }
         *(h8*)(y + ((long)b * HW + row) * C + ch) = o;
     }
@@ -338,22 +338,25 @@ int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, 
                        (_Float16*)y, ldo, M, Ci, Co);
     TCL_LAUNCH_RET();
 }
-size_t tcl_groupnorm_workspace_bytes(int B, int C) { return (size_t)B * 64 * 2 * 4 + (size_t)B * C * 2 * 4 + 256; }
+// workspace: two statistics slots [B][64][2] f32 used alternately by successive calls (slot parity kept per workspace pointer)
+size_t tcl_groupnorm_workspace_bytes(int B, int C) { (void)C; return (size_t)2 * B * 64 * 2 * 4 + 256; }
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {
     const int C = C1 + C2;
     TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C / groups >= 4 && C1 % 8 == 0 && C2 % 8 == 0);
     TCL_CHECK_ARG(C2 == 0 || x2);
-    float* sums = (float*)ws; float* coef = sums + (size_t)B * 64 * 2;
-    if (hipMemsetAsync(sums, 0, (size_t)B * groups * 2 * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    static std::unordered_map<void*, int> parity;           // which slot the next call on this workspace accumulates into
+    int& par = parity[ws];
+    float* cur = (float*)ws + (size_t)par * B * 64 * 2;
+    float* nxt = (float*)ws + (size_t)(par ^ 1) * B * 64 * 2;
+    par ^= 1;
     int blocks = cdiv(HW, 64); if (blocks > 1024) blocks = 1024;
     int rpb = cdiv(HW, blocks); blocks = cdiv(HW, rpb);
-    hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, sums);
-    hipLaunchKernelGGL(k_gn_coef, dim3(cdiv(C, 256), B), dim3(256), 0, st, sums, (const _Float16*)gamma, (const _Float16*)beta, C, groups,
-                       (float)HW * (float)(C / groups), eps, coef);
+    hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, cur);
     long chunks = (long)HW * (C / 8);
     hipLaunchKernelGGL(k_gn_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
-                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, coef, (_Float16*)y, HW, silu);
+                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, cur, nxt, (const _Float16*)gamma, (const _Float16*)beta,
+                       1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu);
     TCL_LAUNCH_RET();
 }
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st) {

@@ -40,6 +40,46 @@ __device__ __forceinline__ unsigned sortable16(_Float16 h) {
     return (b & 0x8000u) ? (unsigned)(unsigned short)~b : (unsigned)(b | 0x8000u);
 }
 
+// Tile epilogue: lane owns src column (lane&31) of each of its 2 column tiles; rows = dst.  Branch-free reduction: packed f16 max
+// over the lane's 32 rows, then the lowest row that attains it (descending scan, last write wins) -- the same key as
+// max_r (sortable(f16(score)) << 32 | ~index): highest f16 score, ties to the lowest concatenated dst index.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <bool TAIL>
+__device__ __forceinline__ void tome_reduce(const float16v (&acc)[2][2], int dj0, int si0, int nb, int na, int bb, int lane,
+                                            unsigned long long* __restrict__ keys) {
+    const _Float16 ninf = (_Float16)(-65504.f);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        half2v hp[2][8];
+        half2v pm = {ninf, ninf};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                half2v h = {(_Float16)acc[a][b][2 * q], (_Float16)acc[a][b][2 * q + 1]};
+                if (TAIL) {
+                    const int d0 = dj0 + a * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2);
+                    h[0] = d0 < nb ? h[0] : ninf;
+                    h[1] = d0 + 1 < nb ? h[1] : ninf;
+                }
+                hp[a][q] = h;
+                pm = __builtin_elementwise_max(pm, h);
+            }
+        const _Float16 m = pm[0] > pm[1] ? pm[0] : pm[1];
+        int idx = 0;
+#pragma unroll
+        for (int a = 1; a >= 0; --a)
+#pragma unroll
+            for (int r = 15; r >= 0; --r) idx = (hp[a][r >> 1][r & 1] == m) ? a * 32 + (r & 3) + 8 * (r >> 2) : idx;
+        const int dj = dj0 + idx;
+        unsigned long long best = 0ull;
+        if (!TAIL || dj < nb) best = ((unsigned long long)sortable16(m) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(bb * nb + dj));
+        unsigned long long other = __shfl_xor(best, 32, 64);
+        best = other > best ? other : best;
+        if ((lane >> 5) == 0 && si0 + b * 32 < na) atomicMax(keys + si0 + b * 32, best);
+    }
+}
+
 // keys[src] = max over (batch, dst) of (sortable(f16(score)) << 32 | ~(batch*nb + dst))
 __global__ __launch_bounds__(256) void k_tome_match(const _Float16* __restrict__ metric, long bstride, int C, const int* __restrict__ a_pos,
                                                     int na, const int* __restrict__ b_pos, int nb, int tiles_src,
@@ -103,25 +143,9 @@ __global__ __launch_bounds__(256) void k_tome_match(const _Float16* __restrict__
         if (kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
     }
-    // lane owns src column (lane&31) of each of its 2 column tiles; rows = dst
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int si = tsrc * 128 + wn * 64 + b * 32 + (lane & 31);
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int dj = tdst * 128 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (dj < nb) {
-                    unsigned long long key = ((unsigned long long)sortable16((_Float16)acc[a][b][r]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(bb * nb + dj));
-                    best = key > best ? key : best;
-                }
-            }
-        unsigned long long other = __shfl_xor(best, 32, 64);
-        best = other > best ? other : best;
-        if ((lane >> 5) == 0 && si < na) atomicMax(keys + si, best);
-    }
+    const int dj0 = tdst * 128 + wm * 64 + 4 * (lane >> 5), si0 = tsrc * 128 + wn * 64 + (lane & 31);
+    if (tdst * 128 + 128 > nb) tome_reduce<true>(acc, dj0, si0, nb, na, bb, lane, keys);      // wave-uniform: last dst tile only
+    else tome_reduce<false>(acc, dj0, si0, nb, na, bb, lane, keys);
 }
 
 // after the sort: order[k] = src local index of rank k (descending score).  Build the maps of SURVEY 8(a) A12/A13:

@@ -72,7 +72,7 @@ class Ops:
         key = (B, c1 + c2)
         ws = self._gn_ws.get(key)
         if ws is None:
-            ws = self._gn_ws[key] = torch.empty(self.L.tcl_groupnorm_workspace_bytes(B, c1 + c2), dtype=torch.uint8, device=self.dev)
+            ws = self._gn_ws[key] = torch.zeros(self.L.tcl_groupnorm_workspace_bytes(B, c1 + c2), dtype=torch.uint8, device=self.dev)   # zeroed once
         y = self.empty(B * HW, c1 + c2)
         self.L.tcl_groupnorm_f16(x1, c1, x2 if x2 is not None else 0, c2, gamma, beta, y, B, HW, groups, eps, int(silu), ws, stream())
         return y

@@ -226,7 +226,7 @@ template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128 ? 2 : BM * BN < 128 * 128 ? 4 : (STAGES == 2 ? 4 : 3)) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                      _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
-                                                     ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part) {
+                                                     ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part, int xcd_n) {
     constexpr int KB = 32;                                  // K per step
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int ROWB = KB * 2;                            // bytes per LDS row (64)
@@ -234,11 +234,22 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
     constexpr int A_IT = BM / 16 / 4, B_IT = BN / 16 / 4;   // 1-KiB pieces (16 rows) per wave per operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tgrid = ((tiles_m + 7) >> 3) * 8 * tiles_n;        // blocks per K-split
-    const int split = blockIdx.x / tgrid;
-    const int bid = blockIdx.x - split * tgrid, xcd = bid & 7, j = bid >> 3;
-    const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
-    if (tm >= tiles_m) return;
+    // XCD-aware tile order (block id % 8 = XCD): normally XCD x owns the M-tiles == x (mod 8) and walks N fastest, so an A panel
+    // stays in one L2 and W (small) is resident in all of them; xcd_n swaps the roles for weight-dominated problems (N > M), where
+    // each W panel should be fetched from HBM by one XCD only.
+    int tm, tn, split;
+    if (!xcd_n) {
+        const int tgrid = ((tiles_m + 7) >> 3) * 8 * tiles_n;        // blocks per K-split
+        split = blockIdx.x / tgrid;
+        const int bid = blockIdx.x - split * tgrid, xcd = bid & 7, j = bid >> 3;
+        tn = j % tiles_n; tm = (j / tiles_n) * 8 + xcd;
+    } else {
+        const int tgrid = ((tiles_n + 7) >> 3) * 8 * tiles_m;
+        split = blockIdx.x / tgrid;
+        const int bid = blockIdx.x - split * tgrid, xcd = bid & 7, j = bid >> 3;
+        tm = j % tiles_m; tn = (j / tiles_m) * 8 + xcd;
+    }
+    if (tm >= tiles_m || tn >= tiles_n) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -426,8 +437,11 @@ static int launch_gemm_dma(const _Float16* A, const _Float16* W, const _Float16*
     const int nk_per = cdiv(nk, splits);
     splits = cdiv(nk, nk_per);
     float* part = splits > 1 ? g_ws : nullptr;
-    hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(cdiv(tm, 8) * 8 * tn * splits), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
-                       act, cp, tm, tn, nk_per, part);
+    static const int xcd_mode = getenv("TCL_GEMM_XCDN") ? atoi(getenv("TCL_GEMM_XCDN")) : -1;      // -1 auto, 0/1 forced (experiments)
+    const int xcd_n = xcd_mode < 0 ? (N > M) : xcd_mode;
+    const int grid = (xcd_n ? cdiv(tn, 8) * 8 * tm : cdiv(tm, 8) * 8 * tn) * splits;
+    hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
+                       act, cp, tm, tn, nk_per, part, xcd_n);
     if (part) hipLaunchKernelGGL(k_splitk_finalize, dim3(stream_grid((long)M * N, 256, 4)), dim3(256), 0, st, part, splits, bias, resid, C, M, N, ldc, ldr, act);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }

@@ -25,8 +25,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define KV_TILE 64
 #define V_STRIDE 72   // halves: 144 B = 9 x 16 B (odd) -> the 16-lane groups of a ds_read_b128 are conflict-free
 
+// one_col >= 0: that column (a padding column, >= d) is set to 1 in valid rows (the K panel's ones column for the folded shift)
 __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
-                            _Float16* __restrict__ dst, int Tp, int DP, long total_chunks) {
+                            _Float16* __restrict__ dst, int Tp, int DP, long total_chunks, int one_col) {
     const int cpr = DP / 8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
         int c8 = (int)(i % cpr) * 8; long row = i / cpr; int t = (int)(row % Tp); long bh = row / Tp; int h = (int)(bh % H); long b = bh / H;
@@ -39,14 +40,17 @@ __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] * scale);
         }
+        if (t < T && one_col >= c8 && one_col < c8 + 8) v[one_col - c8] = (_Float16)1.f;
         *(half8*)(dst + i * 8) = v;
     }
 }
-// Vt[b][h][i][p(t)] = V[b][t][h*d + i]; one block per (64 tokens, b*h).  Within every group of 16 keys the two middle blocks of 4
-// are swapped (p swaps bits 2 and 3 of t): the S^T accumulator of the flash kernel leaves lane half hl with keys {4hl..4hl+3,
-// 8+4hl..8+4hl+3} of a group, and with this order those 8 V^T values are one contiguous 16-B LDS read (8*hl .. 8*hl+7).
+// Vt panel, tile-major: Vt[bh][tile][i][p(t)] = V[b][tile*64 + t][h*d + i], rows of V_STRIDE halves (64 keys + pad), so that one
+// 64-key tile is a contiguous LDS image (DPV x V_STRIDE).  Within every group of 16 keys the two middle blocks of 4 are swapped
+// (p swaps bits 2 and 3 of t): the S^T accumulator of the flash kernel leaves lane half hl with keys {4hl..4hl+3, 8+4hl..8+4hl+3}
+// of a group, and with this order those 8 V^T values are one contiguous 16-B LDS read (8*hl .. 8*hl+7).  Row D (when DPV > D) is
+// a row of ones over the valid keys: the PV MFMA then also yields the softmax row sums.
 __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
-                                                 _Float16* __restrict__ vt, int Tp, int DPV) {
+                                                 _Float16* __restrict__ vt, int ntiles, int DPV) {
     extern __shared__ _Float16 tile[];   // [64][DPV+2]
     const int t0 = blockIdx.x * 64, bh = blockIdx.y, h = bh % H; const long b = bh / H;
     const int st = DPV + 2, cpr = DPV / 8;
@@ -60,175 +64,202 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
         for (int j = 0; j < 8; ++j) tile[r * st + c8 + j] = x[j];
     }
     __syncthreads();
+    _Float16* out = vt + ((long)bh * ntiles + blockIdx.x) * DPV * V_STRIDE;
     for (int i = threadIdx.x; i < DPV * 64; i += 256) {
         int dd = i / 64, r = i % 64;
         _Float16 val = tile[r * st + dd];
-        if (dd == d && DPV > d) val = (t0 + r < T) ? (_Float16)1.f : (_Float16)0.f;   // ones row: the PV MFMA also yields the softmax row sums
+        if (dd == d && DPV > d) val = (t0 + r < T) ? (_Float16)1.f : (_Float16)0.f;
         const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-        vt[((long)bh * DPV + dd) * Tp + t0 + pr] = val;
+        out[dd * V_STRIDE + pr] = val;
     }
 }
 
-// One 64-key tile for one wave (32 queries): S^T = K.Q^T, online softmax, O^T += V^T.P^T.
-// LROW: the row sums l come out of the PV MFMA itself through a ones-row that k_pack_vt stores at Vt row D (free padding
-// row when DPV > D), so no VALU adds are spent on them.  Rescaling of O is lazy: only when some query of the wave sees its
-// running max grow by more than 2^6 (wave-uniform branch); P then stays <= 64, far inside f16 range.
-template <int DP, int DPV, bool LROW>
-__device__ __forceinline__ void flash_tile(const _Float16* __restrict__ kt, const _Float16* __restrict__ vt, const half8 (&qf)[DP / 16],
-                                           float16v (&o)[DPV / 32], float& m, float& lsum, int ql, int hl, int kv0, int Tk, bool mask) {
-    constexpr int KS = DP + 8, NQK = DP / 16, NDT = DPV / 32;
-    float16v s[2];
+// Flash kernel.  Block = 4 waves; each wave owns QB blocks of 32 queries (QB = 2 for head_dim 40: the K and V^T fragments read
+// from LDS feed two MFMAs each, which halves the LDS traffic per MFMA -- measured as the co-bottleneck of the one-block version).
+// K/V tiles (64 keys) are contiguous "LDS images" in the panels (K rows padded to KS = DP + 8 halves, V^T rows to V_STRIDE), so
+// staging is pure LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR staging, no ds_write): ring of NSTG slots,
+// prefetch distance NSTG - 1, counted vmcnt + one raw barrier per tile (a __syncthreads() would drain the DMA queue).
+// Per tile and query block: S^T = K.Q^T (swapped operands: lane l owns query l&31, so row max/sum are in-lane + one exchange
+// with lane l+32), online softmax with lazy rescale (only when some running max grows by more than 2^6), P stays in registers
+// as the B operand of O^T += V^T.P^T; row sums come out of the same MFMA through the ones-row of the V^T panel.
+__device__ __attribute__((aligned(16))) unsigned g_flash_zero[64];
+
+template <int D, int DP, int DPV, int QB, int NSTG>
+__global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                                  _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
+                                                  int kv_div, int nqb) {
+    constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
+    constexpr int NQK = DP / 16, NDT = DPV / 32;
+    constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = DPV * V_STRIDE * 2, SBYTES = KBYTES + VBYTES;
+    constexpr int NPIECE = (SBYTES + 1023) / 1024, NPW = (NPIECE + 3) / 4, SSTRIDE = NPIECE * 1024;
+    constexpr bool LROW = DPV > D;
+    constexpr bool FOLD = DP > D && LROW && (D % 16 == 8);        // spare Q/K column D: lanes hl == 1, element 0 of fragment D/16
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
+
+    const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, ql = lane & 31;
+    const int q0 = qb_ * (128 * QB) + wid * (32 * QB);
+    const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
+    const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;      // tiles / tiles without padded keys
+    const char* kbase = (const char*)(Kp + kbh * Tkp * KS);
+    const char* vbase = (const char*)(Vt + kbh * nt * DPV * V_STRIDE);
+    const char* zero = (const char*)g_flash_zero;
+
+    half8 qf[QB][NQK];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int qb = 0; qb < QB; ++qb) {
+        const _Float16* qrow = Qp + (bh * Tqp + q0 + qb * 32 + ql) * DP + 8 * hl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
-        const _Float16* kr = kt + (blk * 32 + ql) * KS + 8 * hl;
-#pragma unroll
-        for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(kr + ks * 16), qf[ks], s[blk], 0, 0, 0);
+        for (int ks = 0; ks < NQK; ++ks) qf[qb][ks] = *(const half8*)(qrow + ks * 16);
     }
-    if (__builtin_amdgcn_readfirstlane((int)mask)) {      // scalar branch: only the last tile has padded keys
+    // DMA: piece p = wid + 4 i covers stage bytes [1024 p, 1024 p + 1024); K image first, V^T image behind it
+    int poff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) poff[i] = (wid + 4 * i) * 1024 + lane * 16;
+#define FLASH_ISSUE(IT)                                                                                                       \
+    {                                                                                                                         \
+        const char* kt_ = kbase + (long)(IT) * KBYTES;                                                                        \
+        const char* vt_ = vbase + (long)(IT) * VBYTES;                                                                        \
+        char* st_ = smem + ((IT) % NSTG) * SSTRIDE;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
+            const int o_ = poff[i];                                                                                           \
+            const char* src_ = o_ < KBYTES ? kt_ + o_ : (o_ < SBYTES ? vt_ + (o_ - KBYTES) : zero);                           \
+            char* dst_ = (wid + 4 * i) < NPIECE ? st_ + (wid + 4 * i) * 1024 : smem + NSTG * SSTRIDE;                            \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
+                                             (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                        \
+        }                                                                                                                     \
+    }
+
+    float16v o[QB][NDT];
+    float m[QB], lsum[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = FOLD ? 0.f : -1e30f; lsum[qb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
+    }
+
+    // ring of NSTG slots, prefetch distance NSTG - 1: tile it+NSTG-1 goes into the slot tile it-1 just left
+    FLASH_ISSUE(0);
+    if (NSTG == 3 && nt > 1) FLASH_ISSUE(1);
+    for (int it = 0; it < nt; ++it) {
+        if (NSTG == 3 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave's pieces of tile it landed; everyone is done with tile it-1
+        if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);
+        const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
+        const _Float16* vt = kt + KV_TILE * KS;
+        const bool mask = __builtin_amdgcn_readfirstlane((int)(it >= nfull));
+        half8 kf[2][NQK];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { int kv = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
-    }
-    float mx = s[0][0];
+            for (int ks = 0; ks < NQK; ++ks) kf[blk][ks] = *(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16);
+        half8 pf[QB][2][2];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+        for (int qb = 0; qb < QB; ++qb) {
+            float16v s[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (__any(mx > m + 6.f)) {                     // lazy rescale (rare after the first tiles)
-        const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        lsum *= alpha;
+            for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-        for (int t = 0; t < NDT; ++t)
+                for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    }
-    half8 pf[2][2];
-    float ps = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - m); if (!LROW) ps += p; pf[blk][r >> 3][r & 7] = (_Float16)p; }
-    if (!LROW) lsum += ps;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 8 * hl;
-#pragma unroll
-            for (int t = 0; t < NDT; ++t) {
-                half8 vf = *(const half8*)(vr + t * 32 * V_STRIDE);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][ss], o[t], 0, 0, 0);
+                for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[blk][ks], qf[qb][ks], s[blk], 0, 0, 0);
             }
+            if (mask) {                                // scalar branch: only the last tile has padded keys
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float ps = 0.f;
+            if (FOLD) {
+                // The running shift m (kept f16-representable) rides in the spare Q column D against a ones column of the K panel, so the
+                // MFMA already returned s - m and the common path is exp2 alone.  Any shift works as long as every key of the row uses
+                // the same one between rescales; it is re-based when the row maximum climbs more than 2^6 above it (and on tile 0).
+                if (it == 0 || __any(mx > 6.f)) {
+                    const float mn = (float)(_Float16)(m[qb] + (it == 0 ? mx : fmaxf(mx, 0.f)));
+                    const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
+                    m[qb] = mn;
+                    if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);            // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
+#pragma unroll
+                    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[blk][r] -= delta;
+                }
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
+            } else {
+                if (__any(mx > m[qb] + 6.f)) {             // lazy rescale (rare after the first tiles)
+                    const float mn = fmaxf(m[qb], mx), alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+                    m[qb] = mn;
+                    lsum[qb] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+                }
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - m[qb]); if (!LROW) ps += p; pf[qb][blk][r >> 3][r & 7] = (_Float16)p; }
+            }
+            if (!LROW) lsum[qb] += ps;
         }
-}
-
-template <int D, int DP, int DPV, int NW>
-__global__ __launch_bounds__(NW * 64, (DP <= 48 && NW == 4) ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
-                                                  _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
-                                                  int kv_div, int nqb) {
-    constexpr int KS = DP + 8;                    // K row stride (halves); (DP+8)/8 odd -> conflict-free b128 reads
-    constexpr int NQK = DP / 16, NDT = DPV / 32;
-    constexpr int KCH = KV_TILE * DP / 8, VCH = DPV * 8;           // 16-B chunks per tile
-    constexpr int NT_ = NW * 64;                                   // threads per block (NW waves x 32 query rows each)
-    constexpr int KIT = (KCH + NT_ - 1) / NT_, VIT = (VCH + NT_ - 1) / NT_;
-    constexpr bool LROW = DPV > D;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Ks = (_Float16*)smem;                         // [2][64][KS]
-    _Float16* Vs = Ks + 2 * KV_TILE * KS;                   // [2][DPV][V_STRIDE]
-
-    const int bid = blockIdx.x, head = bid % H, qb = (bid / H) % nqb, b = bid / (H * nqb);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hl = lane >> 5, ql = lane & 31;
-    const int q0 = qb * (NW * 32) + wid * 32;
-    const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
-    const _Float16* kbase = Kp + kbh * Tkp * DP;
-    const _Float16* vbase = Vt + kbh * DPV * Tkp;
-
-    half8 qf[NQK];
-    {
-        const _Float16* qrow = Qp + (bh * Tqp + q0 + ql) * DP + 8 * hl;
 #pragma unroll
-        for (int ks = 0; ks < NQK; ++ks) qf[ks] = *(const half8*)(qrow + ks * 16);
-    }
-    u32x4 rkA[KIT], rvA[VIT], rkB[KIT], rvB[VIT];      // two staging sets: tile it+1 waits in one while tile it+2 is in flight
-#define FLASH_GLOAD(IT, RK, RV)                                                                                               \
-    {                                                                                                                         \
-        const _Float16* kt_ = kbase + (long)(IT) * KV_TILE * DP;                                                             \
-        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = min(tid + NT_ * i, KCH - 1); RK[i] = *(const u32x4*)(kt_ + c * 8); }   /* clamped: always defined */ \
-        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = min(tid + NT_ * i, VCH - 1); RV[i] = *(const u32x4*)(vbase + (long)(c >> 3) * Tkp + (IT) * KV_TILE + (c & 7) * 8); } \
-    }
-#define FLASH_SSTORE(BUF, RK, RV)                                                                                             \
-    {                                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < KIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= KCH || c < KCH) { int r = c / (DP / 8), c8 = (c % (DP / 8)) * 8; *(u32x4*)(Ks + ((BUF) * KV_TILE + r) * KS + c8) = RK[i]; } } \
-        _Pragma("unroll") for (int i = 0; i < VIT; ++i) { int c = tid + NT_ * i; if ((i + 1) * NT_ <= VCH || c < VCH) { *(u32x4*)(Vs + ((BUF) * DPV + (c >> 3)) * V_STRIDE + (c & 7) * 8) = RV[i]; } } \
-    }
-#define FLASH_TILE(BUF, IT) flash_tile<DP, DPV, LROW>(Ks + (BUF) * KV_TILE * KS, Vs + (BUF) * DPV * V_STRIDE, qf, o, m, lsum, ql, hl, (IT) * KV_TILE, Tk, (IT) >= nfull)
-
-    float16v o[NDT];
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
+            for (int ss = 0; ss < 2; ++ss) {
+                const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 8 * hl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    float m = -1e30f, lsum = 0.f;
-
-    const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;      // tiles without padded keys
-    constexpr bool PF2 = DP <= 80;        // prefetch distance 2 (two register sets) where the register budget allows it
-    FLASH_GLOAD(0, rkA, rvA); FLASH_SSTORE(0, rkA, rvA);
-    if constexpr (PF2) {
-        if (nt > 1) FLASH_GLOAD(1, rkA, rvA);
-        __syncthreads();
-        for (int it = 0; it < nt; it += 2) {
-            // even tile in LDS buffer 0; set A holds tile it+1; tile it+2 goes into set B (two iterations to land)
-            if (it + 2 < nt) FLASH_GLOAD(it + 2, rkB, rvB);
-            FLASH_TILE(0, it);
-            if (it + 1 < nt) FLASH_SSTORE(1, rkA, rvA);
-            __syncthreads();
-            if (it + 1 >= nt) break;
-            if (it + 3 < nt) FLASH_GLOAD(it + 3, rkA, rvA);
-            FLASH_TILE(1, it + 1);
-            if (it + 2 < nt) FLASH_SSTORE(0, rkB, rvB);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-        for (int it = 0; it < nt; ++it) {
-            const int cur = it & 1;
-            if (it + 1 < nt) FLASH_GLOAD(it + 1, rkA, rvA);
-            FLASH_TILE(cur, it);
-            if (it + 1 < nt) FLASH_SSTORE(cur ^ 1, rkA, rvA);
-            __syncthreads();
-        }
-    }
-#undef FLASH_TILE
-#undef FLASH_GLOAD
-#undef FLASH_SSTORE
-    // ---- epilogue
-    float l;
-    if (LROW) {      // l sits in O^T row D: tile D/32, register group (D%32)/8 (D%8 == 0), lanes with hl == (D%8)/4 == 0
-        constexpr int TL = D / 32, RG = (D % 32) / 8;
-        l = o[TL][4 * RG];
-        l = __shfl(l, ql, 64);                    // broadcast from the hl == 0 half
-    } else {
-        l = lsum + __shfl_xor(lsum, 32, 64);
-    }
-    const float inv = 1.f / l;
-    const int q = q0 + ql;
-    if (q < Tq) {
-        _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
+                for (int t = 0; t < NDT; ++t) {
+                    const half8 vf = *(const half8*)(vr + t * 32 * V_STRIDE);
 #pragma unroll
-        for (int t = 0; t < NDT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int dd = t * 32 + 8 * g + 4 * hl;
-                if (dd < d) {
-                    half4 w = {(_Float16)(o[t][4 * g] * inv), (_Float16)(o[t][4 * g + 1] * inv), (_Float16)(o[t][4 * g + 2] * inv), (_Float16)(o[t][4 * g + 3] * inv)};
-                    *(half4*)(orow + dd) = w;
+                    for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][blk][ss], o[qb][t], 0, 0, 0);
                 }
             }
+    }
+#undef FLASH_ISSUE
+    // ---- epilogue
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l;
+        if (LROW) {      // l sits in O^T row D: tile D/32, register group (D%32)/8 (D%8 == 0), lanes with hl == (D%8)/4 == 0
+            constexpr int TL = D / 32, RG = (D % 32) / 8;
+            l = o[qb][TL][4 * RG];
+            l = __shfl(l, ql, 64);                    // broadcast from the hl == 0 half
+        } else {
+            l = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
+        }
+        const float inv = 1.f / l;
+        const int q = q0 + qb * 32 + ql;
+        if (q < Tq) {
+            _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int dd = t * 32 + 8 * g + 4 * hl;
+                    if (dd < d) {
+                        half4 w = {(_Float16)(o[qb][t][4 * g] * inv), (_Float16)(o[qb][t][4 * g + 1] * inv), (_Float16)(o[qb][t][4 * g + 2] * inv), (_Float16)(o[qb][t][4 * g + 3] * inv)};
+                        *(half4*)(orow + dd) = w;
+                    }
+                }
+        }
     }
 }
 
@@ -237,17 +268,18 @@ __global__ __launch_bounds__(NW * 64, (DP <= 48 && NW == 4) ? 3 : 2) void k_flas
 struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
 static FlashProf g_prof;
 
-template <int D, int DP, int DPV, int NW>
+template <int D, int DP, int DPV, int QB, int NSTG>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
-    const size_t lds = (size_t)2 * KV_TILE * (DP + 8) * 2 + (size_t)2 * DPV * V_STRIDE * 2;
+    constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
+    const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    const int nqb = Tqp / (NW * 32);
+    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, NW>), dim3(B * H * nqb), dim3(NW * 64), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -274,10 +306,10 @@ int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches)
     return TCL_OK;
 }
 
-// panel sizes: Tqp = ceil128(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d)
+// panel sizes: Tqp = ceil256(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d); K rows DP+8 halves, V^T tiles DPV x V_STRIDE
 size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 256) * rup(d, 16) * 2 + 256; }
 size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
-    return ((size_t)Bkv * H * rup(Tk, 64) * rup(d, 16) + (size_t)Bkv * H * rup(d, 32) * rup(Tk, 64)) * 2 + 256;
+    return ((size_t)Bkv * H * rup(Tk, 64) * (rup(d, 16) + 8) + (size_t)Bkv * H * (rup(Tk, 64) / 64) * rup(d, 32) * V_STRIDE) * 2 + 2048;
 }
 
 // softmax(Q K^T * scale) V per head.  q/k/v point at head 0 of batch 0; row strides ld* and batch strides *bs in halves.
@@ -289,24 +321,25 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
     TCL_CHECK_ARG(d == 40 || d == 80 || d == 160);
     TCL_CHECK_ARG(!pack_kv || (k && v));
-    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), DPV = rup(d, 32), Bkv = B / kv_div;
+    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
     _Float16* Kp = (_Float16*)ws_kv;
-    _Float16* Vt = Kp + (size_t)Bkv * H * Tkp * DP;
-    long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (DP / 8);
+    _Float16* Vt = Kp + (((size_t)Bkv * H * Tkp * KS + 511) / 512) * 512;        // 1-KiB aligned
+    long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (KS / 8);
     hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,
-                       scale * 1.4426950408889634f, Qp, Tqp, DP, qc);
+                       scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1);
     if (pack_kv) {
-        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, DP, kc);
-        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp, DPV);
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, KS, kc,
+                           d == 40 ? d : -1);
+        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV);
     }
-    static const int nw8 = getenv("TCL_FLASH_NW") ? atoi(getenv("TCL_FLASH_NW")) == 8 : 0;
-    const bool big = nw8 && Tq >= 2048;          // 8-wave blocks (256 query rows) halve the K/V traffic per query on long sequences
-    if (d == 40) return big ? launch_flash<40, 48, 64, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
-                            : launch_flash<40, 48, 64, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 80) return big ? launch_flash<80, 80, 96, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
-                            : launch_flash<80, 80, 96, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    return launch_flash<160, 160, 160, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    // d = 40: two query blocks per wave (shared K/V fragments) when the grid still fills the chip several times over, else one;
+    // d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
+    const bool qb2 = (long)B * H * (Tqp / 256) >= 1024;
+    if (d == 40) return qb2 ? launch_flash<40, 48, 64, 2, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                            : launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
 }
 
 }  // extern "C"

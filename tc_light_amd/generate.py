@@ -67,25 +67,36 @@ class Generator:
             raise NotImplementedError(f"Noise mode '{c.noise_mode}' is not supported.")
 
     # ------------------------------------------------------------------ one UNet evaluation with CFG
-    def _unet_xy(self, x, cc, frames_idx, text, t, noises):
-        """pred_noise on an xy chunk (generate.py:220-224, 288-352): frames_idx = local frame ids."""
-        L, F = self.L, len(frames_idx)
-        idx = torch.tensor(frames_idx, dtype=I32, device=self.dev)
-        xin = torch.empty(2 * F, self.h, self.w, 8, dtype=H16, device=self.dev)
-        L.tcl_pack_latents_f16(x, cc, idx, F, 0, 0, 0, self.h, self.w, xin, stream())
-        eps = self.unet.forward_nhwc(xin, F, self.h, self.w, t, text)
-        L.tcl_unpack_cfg_f16(eps, idx, F, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
+    def _unet_xy(self, x, cc, chunks, text, t, noises):
+        """pred_noise on the xy chunks of one step (generate.py:220-224, 288-352): chunks = lists of local frame ids, reference order.
+        The UNet runs them through `forward_many` (deep levels batched over the chunks, see unet.py)."""
+        L = self.L
+        idxs, xs = [], []
+        for frames_idx in chunks:
+            F = len(frames_idx)
+            idx = torch.tensor(frames_idx, dtype=I32, device=self.dev)
+            xin = torch.empty(2 * F, self.h, self.w, 8, dtype=H16, device=self.dev)
+            L.tcl_pack_latents_f16(x, cc, idx, F, 0, 0, 0, self.h, self.w, xin, stream())
+            idxs.append(idx); xs.append(xin)
+        eps = self.unet.forward_many(xs, [len(c) for c in chunks], self.h, self.w, t, text)
+        for idx, e in zip(idxs, eps):
+            L.tcl_unpack_cfg_f16(e, idx, len(idx), 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
 
-    def _unet_yt(self, x_full, cc_full, item, nt_full, text_t, t):
-        """pred_noise on a yt chunk: 'n c h w -> w c n h' over a frame window (generate.py:265-273)."""
-        sl, nwin, cols, scale_upto, nkeep = item
-        L, F = self.L, len(cols)
-        idx = torch.tensor(cols, dtype=I32, device=self.dev)
-        xin = torch.empty(2 * F, nwin, self.h, 8, dtype=H16, device=self.dev)
-        L.tcl_pack_latents_f16(x_full, cc_full, idx, F, 1, sl, nwin, self.h, self.w, xin, stream())
-        eps = self.unet.forward_nhwc(xin, F, nwin, self.h, t, text_t)
-        L.tcl_unpack_cfg_f16(eps, idx, F, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
-                             nkeep, nt_full, stream())
+    def _unet_yt(self, x_full, cc_full, items, nt_full, text_t, t):
+        """pred_noise on yt chunks: 'n c h w -> w c n h' over a frame window (generate.py:265-273).  items share one window length."""
+        L = self.L
+        nwin = items[0][1]
+        idxs, xs = [], []
+        for sl, _, cols, _, _ in items:
+            F = len(cols)
+            idx = torch.tensor(cols, dtype=I32, device=self.dev)
+            xin = torch.empty(2 * F, nwin, self.h, 8, dtype=H16, device=self.dev)
+            L.tcl_pack_latents_f16(x_full, cc_full, idx, F, 1, sl, nwin, self.h, self.w, xin, stream())
+            idxs.append(idx); xs.append(xin)
+        eps = self.unet.forward_many(xs, [len(it[2]) for it in items], nwin, self.h, t, text_t)
+        for (sl, _, cols, scale_upto, nkeep), idx, e in zip(items, idxs, eps):
+            L.tcl_unpack_cfg_f16(e, idx, len(cols), 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
+                                 nkeep, nt_full, stream())
 
     def _yt_items(self, w_chunks):
         """(window start, length, columns, scale_upto, nkeep) in the reference's loop order (generate.py:265-278)."""
@@ -114,12 +125,11 @@ class Generator:
         cc_full = d.gather_frames(concat_conds, self.n_total) if c.alpha_t > 0 else None
         lo, hi = d.range(self.n_total)
         for i, t in enumerate(sch.timesteps.tolist()):
-            for chunk in xy_sampler.get_chunks(n_local):
-                self._unet_xy(x, concat_conds, chunk, conds, t, noises)
+            self._unet_xy(x, concat_conds, xy_sampler.get_chunks(n_local), conds, t, noises)
             if c.alpha_t > 0:
                 items = self._yt_items(yt_sampler.get_chunks(self.w))
                 nt = sharded_temporal_pass(d, x, cc_full, self.n_total, items,
-                                           lambda xf, cf, it, out: self._unet_yt(xf, cf, it, out, conds_t, t))
+                                           lambda xf, cf, its, out: self._unet_yt(xf, cf, its, out, conds_t, t))
                 noises_t.copy_(nt)
                 self.L.tcl_adain_fuse_f16(noises_t, noises, n_local * 4, self.h * self.w, float(alphas[i]), stream())
             z = None

@@ -66,14 +66,19 @@ class Dist:
 
 
 def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=None):
-    """yt-plane pass.  items: list of (window_start, window_len, column_chunk, scale_upto) identical on every rank;
-    compute(x_full, cc_full, item, noises_t_full) writes the item's columns for the window's frames into noises_t_full.
-    Returns this rank's frame block of the assembled noises_t."""
+    """yt-plane pass.  items: list of (window_start, window_len, column_chunk, scale_upto, nkeep) identical on every rank;
+    compute(x_full, cc_full, items, noises_t_full) takes this rank's items of ONE window (same window length, reference order) and
+    writes their columns for the window's frames into noises_t_full.  Returns this rank's frame block of the assembled noises_t."""
     if x_full is None:
         x_full = d.gather_frames(x_local, n_total)
     nt_full = torch.zeros_like(x_full)
-    for it in d.my_items(items):
-        compute(x_full, cc_full, it, nt_full)
+    mine, group = d.my_items(items), []
+    for it in mine + [None]:                       # consecutive items of one window go to the UNet together
+        if group and (it is None or it[:2] != group[0][:2]):
+            compute(x_full, cc_full, group, nt_full)
+            group = []
+        if it is not None:
+            group.append(it)
     d.reduce_full(nt_full)
     lo, hi = d.range(n_total)
     return nt_full[lo:hi]

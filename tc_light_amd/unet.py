@@ -254,12 +254,16 @@ class UNetEngine:
         return o.gemm(h, blk["pout"][0], blk["pout"][1], resid=x)
 
     # ------------------------------------------------------------------ forward
-    def forward_nhwc(self, x_in, F, Hh, Ww, t, text):
-        """x_in [2F, Hh, Ww, 8] f16 (latents | concat_conds); text [2, L, 768] f16 (uncond, cond). -> eps [2F, Hh, Ww, 4] f16."""
+    # The UNet is run in three segments.  VidToMe merges tokens only where downsample <= max_downsample (levels 0 and 1 of SD-1.5):
+    # only those transformer blocks carry a global-token bank, i.e. a chunk-to-chunk dependency (patch.py:59-82).  Everything
+    # between the second downsampler and the second upsampler (levels 2, 3 and the mid block) is per-sample work with no state,
+    # so `forward_many` runs the shallow-down segment chunk by chunk (bank order = chunk order, as in the reference loop), then
+    # the deep segment ONCE over all chunks stacked on the batch axis (1280-channel GEMMs/convs with 8-31x more rows, weights
+    # streamed once instead of once per chunk), then the shallow-up segment chunk by chunk in the same order.  Every block still
+    # sees the chunks in the reference order with the reference inputs; only the interleaving between blocks changes.
+    def _shallow_down(self, x_in, F, Hh, Ww, tproj, text):
         o, L, w = self.ops, self.L, self.w
         B = 2 * F
-        tproj = self._temb(t)
-        self.tome.begin_forward(F, (Hh, Ww))
         col = o.empty(B * Hh * Ww, 128)
         L.tcl_im2col3x3_small_f16(x_in, col, B, Hh, Ww, w["conv_in"][2], 128, stream())
         h = o.gemm(col, w["conv_in"][0], w["conv_in"][1])
@@ -267,12 +271,34 @@ class UNetEngine:
         sizes = [(Hh, Ww)]
         skips = [(h, 320)]
         hh, ww, c = Hh, Ww, 320
-        for i, co in enumerate(sd15.BLOCK_OUT):
+        for i in range(2):
+            co = sd15.BLOCK_OUT[i]
+            for j in range(2):
+                h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
+                c = co
+                h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+                skips.append((h, c))
+            h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
+            self._fl(2.0 * B * hh2 * ww2 * 9 * c * c)
+            hh, ww = hh2, ww2
+            sizes.append((hh, ww))
+            skips.append((h, c))
+        return dict(h=h, skips=skips, sizes=sizes, F=F)
+
+    def _deep(self, h, Ftot, hh, ww, up_to, tproj, text):
+        """h [2*Ftot, hh, ww, 640] (all unconditional samples first, then all conditional ones) -> [2*Ftot, *up_to, 1280]."""
+        o, w = self.ops, self.w
+        B = 2 * Ftot
+        sizes = [(hh, ww)]
+        skips = [(h, 640)]
+        c = 640
+        for i in (2, 3):
+            co = sd15.BLOCK_OUT[i]
             for j in range(2):
                 h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
                 c = co
                 if i < 3:
-                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Ftot, hh, ww, text)
                 skips.append((h, c))
             if i < 3:
                 h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
@@ -281,22 +307,73 @@ class UNetEngine:
                 sizes.append((hh, ww))
                 skips.append((h, c))
         h = self._resblock("mid_block.resnets.0.", h, B, hh, ww, tproj)
-        h = self._transformer("mid_block.attentions.0.", h, B, F, hh, ww, text)
+        h = self._transformer("mid_block.attentions.0.", h, B, Ftot, hh, ww, text)
         h = self._resblock("mid_block.resnets.1.", h, B, hh, ww, tproj)
-        level = 3
-        for i, co in enumerate(sd15.BLOCK_OUT[::-1]):
+        for i in (0, 1):
+            co = sd15.BLOCK_OUT[::-1][i]
             for j in range(3):
                 sk, cs = skips.pop()
                 h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
                 if i > 0:
-                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, Ftot, hh, ww, text)
+            target = sizes[0] if i == 0 else up_to
+            h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=target)          # nearest upsample fused in the gather
+            self._fl(2.0 * B * hh2 * ww2 * 9 * co * co)
+            hh, ww = hh2, ww2
+        return h
+
+    def _shallow_up(self, h, st, tproj, text):
+        o, w = self.ops, self.w
+        F, skips, sizes = st["F"], list(st["skips"][:-1]), st["sizes"]       # the last shallow skip (down1 output) was consumed by _deep
+        B = 2 * F
+        hh, ww = sizes[1]
+        for i in (2, 3):
+            co = sd15.BLOCK_OUT[::-1][i]
+            for j in range(3):
+                sk, cs = skips.pop()
+                h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
+                h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
             if i < 3:
-                level -= 1
-                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[level])   # nearest upsample fused in the gather
+                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[0])
                 self._fl(2.0 * B * hh2 * ww2 * 9 * co * co)
                 hh, ww = hh2, ww2
         hn = o.groupnorm(h, 320, *w["norm_out"], B, hh * ww, 1e-5, True)
         eps, _, _ = o.conv3x3(hn, B, hh, ww, 320, *w["conv_out"])
         self._fl(2.0 * B * hh * ww * 9 * 320 * 4)
-        self.tome.end_forward()
         return eps
+
+    def forward_many(self, xs, Fs, Hh, Ww, t, text):
+        """xs: list of [2F_i, Hh, Ww, 8] f16 chunk inputs in the reference's chunk order; -> list of eps [2F_i, Hh, Ww, 4]."""
+        tproj = self._temb(t)
+        tome = self.tome
+        states = []
+        for x_in, F in zip(xs, Fs):
+            tome.begin_forward(F, (Hh, Ww))                      # this chunk's lock-step draws (patch.py:206-231)
+            st = self._shallow_down(x_in, F, Hh, Ww, tproj, text)
+            st["draw"] = (tome.randf, tome.coin)
+            states.append(st)
+        h2, w2 = states[0]["sizes"][2]
+        h1, w1 = states[0]["sizes"][1]
+        Ftot = sum(Fs)
+        if len(xs) == 1:
+            hd = states[0]["h"]
+        else:       # activations are [samples * pixels, C]: stack all unconditional samples, then all conditional ones
+            n2 = h2 * w2
+            hd = torch.cat([st["h"][:st["F"] * n2] for st in states] + [st["h"][st["F"] * n2:] for st in states])
+        tome.F, tome.size = Ftot, (Hh, Ww)
+        hu = self._deep(hd, Ftot, h2, w2, (h1, w1), tproj, text)
+        outs, off, n1 = [], 0, h1 * w1
+        for st in states:
+            F = st["F"]
+            hi = hu if len(xs) == 1 else torch.cat([hu[off * n1:(off + F) * n1], hu[(Ftot + off) * n1:(Ftot + off + F) * n1]])
+            off += F
+            tome.F, tome.size = F, (Hh, Ww)
+            tome.randf, tome.coin = st["draw"]
+            outs.append(self._shallow_up(hi, st, tproj, text))
+            st.clear()
+        tome.end_forward()
+        return outs
+
+    def forward_nhwc(self, x_in, F, Hh, Ww, t, text):
+        """x_in [2F, Hh, Ww, 8] f16 (latents | concat_conds); text [2, L, 768] f16 (uncond, cond). -> eps [2F, Hh, Ww, 4] f16."""
+        return self.forward_many([x_in], [F], Hh, Ww, t, text)[0]

@@ -104,7 +104,7 @@ class VidToMe:
             L.tcl_gather_rows_f16(x, F * N * C, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
         else:
             mrg1 = unm1 = None
-            local, TL = x, N
+            local, TL = x.view(2, N, C), N              # F == 1: nothing to merge locally; keep the [2, T, C] bank layout
         if not a["merge_global"]:
             return local, unm1, TL
         bank = self.banks.get(name)

@@ -28,8 +28,14 @@ def _items(n_total, w, win=64):
     return items
 
 
-def _compute(x_full, cc_full, item, out):
-    """Stand-in for a yt-plane UNet call: a deterministic function of the window's frames and the chunk's columns."""
+def _compute(x_full, cc_full, items, out):
+    """Stand-in for the yt-plane UNet calls of one window: a deterministic function of the window's frames and each chunk's columns."""
+    assert len({it[:2] for it in items}) == 1           # one window per call
+    for item in items:
+        _compute_one(x_full, cc_full, item, out)
+
+
+def _compute_one(x_full, cc_full, item, out):
     sl, nwin, cols, up, nkeep = item
     blk = x_full[sl:sl + nwin][:, :, :, cols] * 0.5 + cc_full[sl:sl + nwin][:, :, :, cols] * 0.25 + (sl + 1) * 0.01
     scale = torch.ones(nwin, 1, 1, 1)
@@ -77,5 +83,5 @@ def test_sharded_temporal_pass_world2():
         ref = torch.zeros_like(x)
         for it in _items(n_total, 10):
             sl, nwin, cols, up, nkeep = it
-            _compute(x, cc, (sl, nwin, cols, up, nwin), ref)     # write ALL frames, sequentially, like generate.py:265-278
+            _compute_one(x, cc, (sl, nwin, cols, up, nwin), ref)     # write ALL frames, sequentially, like generate.py:265-278
         assert torch.equal(got, ref)

@@ -69,34 +69,28 @@ class Generator:
     # ------------------------------------------------------------------ one UNet evaluation with CFG
     def _unet_xy(self, x, cc, chunks, text, t, noises):
         """pred_noise on the xy chunks of one step (generate.py:220-224, 288-352): chunks = lists of local frame ids, reference order.
-        The UNet runs them through `forward_many` (deep levels batched over the chunks, see unet.py)."""
+        All chunks go through the UNet in one block-major pass (`forward_many`, see unet.py): one pack, one unpack."""
         L = self.L
-        idxs, xs = [], []
-        for frames_idx in chunks:
-            F = len(frames_idx)
-            idx = torch.tensor(frames_idx, dtype=I32, device=self.dev)
-            xin = torch.empty(2 * F, self.h, self.w, 8, dtype=H16, device=self.dev)
-            L.tcl_pack_latents_f16(x, cc, idx, F, 0, 0, 0, self.h, self.w, xin, stream())
-            idxs.append(idx); xs.append(xin)
-        eps = self.unet.forward_many(xs, [len(c) for c in chunks], self.h, self.w, t, text)
-        for idx, e in zip(idxs, eps):
-            L.tcl_unpack_cfg_f16(e, idx, len(idx), 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
+        frames = [f for c in chunks for f in c]
+        n = len(frames)
+        idx = torch.tensor(frames, dtype=I32, device=self.dev)
+        xin = torch.empty(2 * n, self.h, self.w, 8, dtype=H16, device=self.dev)
+        L.tcl_pack_latents_f16(x, cc, idx, n, 0, 0, 0, self.h, self.w, xin, stream())
+        eps = self.unet.forward_many(xin, [len(c) for c in chunks], self.h, self.w, t, text)
+        L.tcl_unpack_cfg_f16(eps, idx, n, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
 
     def _unet_yt(self, x_full, cc_full, items, nt_full, text_t, t):
-        """pred_noise on yt chunks: 'n c h w -> w c n h' over a frame window (generate.py:265-273).  items share one window length."""
+        """pred_noise on the yt chunks of one frame window: 'n c h w -> w c n h' (generate.py:265-273); items share (start, length)."""
         L = self.L
-        nwin = items[0][1]
-        idxs, xs = [], []
-        for sl, _, cols, _, _ in items:
-            F = len(cols)
-            idx = torch.tensor(cols, dtype=I32, device=self.dev)
-            xin = torch.empty(2 * F, nwin, self.h, 8, dtype=H16, device=self.dev)
-            L.tcl_pack_latents_f16(x_full, cc_full, idx, F, 1, sl, nwin, self.h, self.w, xin, stream())
-            idxs.append(idx); xs.append(xin)
-        eps = self.unet.forward_many(xs, [len(it[2]) for it in items], nwin, self.h, t, text_t)
-        for (sl, _, cols, scale_upto, nkeep), idx, e in zip(items, idxs, eps):
-            L.tcl_unpack_cfg_f16(e, idx, len(cols), 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
-                                 nkeep, nt_full, stream())
+        sl, nwin, _, scale_upto, nkeep = items[0]
+        cols = [c for it in items for c in it[2]]
+        n = len(cols)
+        idx = torch.tensor(cols, dtype=I32, device=self.dev)
+        xin = torch.empty(2 * n, nwin, self.h, 8, dtype=H16, device=self.dev)
+        L.tcl_pack_latents_f16(x_full, cc_full, idx, n, 1, sl, nwin, self.h, self.w, xin, stream())
+        eps = self.unet.forward_many(xin, [len(it[2]) for it in items], nwin, self.h, t, text_t)
+        L.tcl_unpack_cfg_f16(eps, idx, n, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
+                             nkeep, nt_full, stream())
 
     def _yt_items(self, w_chunks):
         """(window start, length, columns, scale_upto, nkeep) in the reference's loop order (generate.py:265-278)."""

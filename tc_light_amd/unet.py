@@ -213,29 +213,37 @@ class UNetEngine:
             hit = blk["text_kv"][key] = dict(kv=kv, ws=ws, packed=False, L=Lt, text=text)
         return hit
 
-    def _transformer(self, p, x, B, F, Hh, Ww, text):
+    def _transformer(self, p, x, B, Fs, Hh, Ww, text):
+        """x [B*N, C] with B = 2*sum(Fs) samples: the unconditional samples of all chunks (chunk order), then the conditional ones.
+        Everything is batched over the chunks except attn1 of the merging levels, which runs chunk by chunk in the reference order
+        because each chunk's merge uses -- and updates -- this block's global-token bank (patch.py:59-82)."""
         o, L, blk = self.ops, self.L, self.tfm[p]
         C, N, Hd = blk["c"], Hh * Ww, sd15.HEADS
         d = C // Hd
         M = B * N
+        Ftot = B // 2
         hn = o.groupnorm(x, C, *blk["gn"], B, N, 1e-6, False)
         h = o.gemm(hn, blk["pin"][0], blk["pin"][1])
         self._fl(2.0 * M * C * C * 2)
         # ---- attn1 over VidToMe-merged tokens (patch.py:161-179)
         n1 = o.layernorm(h, *blk["ln"][0], M, C)
-        mg = self.tome.compute_merge(p, n1, F, N, C, Hh * Ww)
-        if mg is None:                                          # downsample > max_downsample: per-frame attention
+        if not self.tome.merges(N):                             # downsample > max_downsample: per-frame attention
             qkv = o.gemm(n1, blk["qkv"])
             a = o.attention(qkv, 3 * C, N * 3 * C, qkv[:, C:], 3 * C, N * 3 * C, qkv[:, 2 * C:], 3 * C, N * 3 * C, B, Hd, N, N, d)
             h = o.gemm(a, blk["o1"][0], blk["o1"][1], resid=h)
             self._fl(2.0 * M * C * C * 4 + 4.0 * B * N * N * C)
         else:
-            merged, unm, T = mg                                   # merged [2, T, C]
-            qkv = o.gemm(merged, blk["qkv"], M=2 * T)
-            a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
-            y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
-            L.tcl_gather_add_rows_f16(h, F * N * C, y, T * C, unm if unm is not None else 0, 2, F * N, C, stream())
-            self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
+            off, xbs = 0, Ftot * N * C                          # a chunk's conditional rows sit xbs elements after its unconditional ones
+            for ci, F in enumerate(Fs):
+                self.tome.select_chunk(ci)
+                merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs)     # merged [2, T, C]
+                qkv = o.gemm(merged, blk["qkv"], M=2 * T)
+                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
+                y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
+                L.tcl_gather_add_rows_f16(h[off * N:], xbs, y, T * C, unm if unm is not None else 0, 2, F * N, C, stream())
+                self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
+                off += F
+        F = Ftot
         # ---- attn2: text cross-attention on the full tokens
         n2 = o.layernorm(h, *blk["ln"][1], M, C)
         q = o.gemm(n2, blk["q2"])
@@ -254,51 +262,35 @@ class UNetEngine:
         return o.gemm(h, blk["pout"][0], blk["pout"][1], resid=x)
 
     # ------------------------------------------------------------------ forward
-    # The UNet is run in three segments.  VidToMe merges tokens only where downsample <= max_downsample (levels 0 and 1 of SD-1.5):
-    # only those transformer blocks carry a global-token bank, i.e. a chunk-to-chunk dependency (patch.py:59-82).  Everything
-    # between the second downsampler and the second upsampler (levels 2, 3 and the mid block) is per-sample work with no state,
-    # so `forward_many` runs the shallow-down segment chunk by chunk (bank order = chunk order, as in the reference loop), then
-    # the deep segment ONCE over all chunks stacked on the batch axis (1280-channel GEMMs/convs with 8-31x more rows, weights
-    # streamed once instead of once per chunk), then the shallow-up segment chunk by chunk in the same order.  Every block still
-    # sees the chunks in the reference order with the reference inputs; only the interleaving between blocks changes.
-    def _shallow_down(self, x_in, F, Hh, Ww, tproj, text):
+    # All chunks of a denoising step go through the UNet in ONE pass, stacked on the batch axis (unconditional samples of every
+    # chunk first, then the conditional ones).  The only chunk-to-chunk dependency of the reference loop (generate.py:220-224) is
+    # the global-token bank of the merging transformer blocks (levels 0 and 1; patch.py:59-82): chunk c's attn1 in block b needs
+    # the bank block b was left with by chunk c-1.  Running block-major (all chunks through block b, then block b+1) keeps both
+    # orders -- data flow per chunk, bank order per block -- so inside a block only attn1 loops over the chunks; ResNet blocks,
+    # norms, cross-attention, feed-forward and the non-merging levels see 8-31x more rows per GEMM and one launch instead of one
+    # per chunk, and every weight matrix is streamed once per step.
+    def forward_many(self, x_in, Fs, Hh, Ww, t, text):
+        """x_in [2*Ftot, Hh, Ww, 8] f16 (latents | concat_conds; Ftot = sum(Fs) samples in chunk order, twice: uncond, cond);
+        text [2, L, 768] f16 (uncond, cond).  Fs: chunk lengths in the reference's chunk order.  -> eps [2*Ftot, Hh, Ww, 4] f16."""
         o, L, w = self.ops, self.L, self.w
-        B = 2 * F
+        Ftot = sum(Fs)
+        B = 2 * Ftot
+        tproj = self._temb(t)
+        self.tome.begin_step(Fs, (Hh, Ww))                      # every chunk's lock-step draws, in chunk order (patch.py:206-231)
         col = o.empty(B * Hh * Ww, 128)
         L.tcl_im2col3x3_small_f16(x_in, col, B, Hh, Ww, w["conv_in"][2], 128, stream())
         h = o.gemm(col, w["conv_in"][0], w["conv_in"][1])
+        del col
         self._fl(2.0 * B * Hh * Ww * 72 * 320)
         sizes = [(Hh, Ww)]
         skips = [(h, 320)]
         hh, ww, c = Hh, Ww, 320
-        for i in range(2):
-            co = sd15.BLOCK_OUT[i]
-            for j in range(2):
-                h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
-                c = co
-                h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
-                skips.append((h, c))
-            h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
-            self._fl(2.0 * B * hh2 * ww2 * 9 * c * c)
-            hh, ww = hh2, ww2
-            sizes.append((hh, ww))
-            skips.append((h, c))
-        return dict(h=h, skips=skips, sizes=sizes, F=F)
-
-    def _deep(self, h, Ftot, hh, ww, up_to, tproj, text):
-        """h [2*Ftot, hh, ww, 640] (all unconditional samples first, then all conditional ones) -> [2*Ftot, *up_to, 1280]."""
-        o, w = self.ops, self.w
-        B = 2 * Ftot
-        sizes = [(hh, ww)]
-        skips = [(h, 640)]
-        c = 640
-        for i in (2, 3):
-            co = sd15.BLOCK_OUT[i]
+        for i, co in enumerate(sd15.BLOCK_OUT):
             for j in range(2):
                 h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
                 c = co
                 if i < 3:
-                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Ftot, hh, ww, text)
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text)
                 skips.append((h, c))
             if i < 3:
                 h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
@@ -307,73 +299,27 @@ class UNetEngine:
                 sizes.append((hh, ww))
                 skips.append((h, c))
         h = self._resblock("mid_block.resnets.0.", h, B, hh, ww, tproj)
-        h = self._transformer("mid_block.attentions.0.", h, B, Ftot, hh, ww, text)
+        h = self._transformer("mid_block.attentions.0.", h, B, Fs, hh, ww, text)
         h = self._resblock("mid_block.resnets.1.", h, B, hh, ww, tproj)
-        for i in (0, 1):
-            co = sd15.BLOCK_OUT[::-1][i]
+        level = 3
+        for i, co in enumerate(sd15.BLOCK_OUT[::-1]):
             for j in range(3):
                 sk, cs = skips.pop()
                 h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
+                del sk
                 if i > 0:
-                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, Ftot, hh, ww, text)
-            target = sizes[0] if i == 0 else up_to
-            h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=target)          # nearest upsample fused in the gather
-            self._fl(2.0 * B * hh2 * ww2 * 9 * co * co)
-            hh, ww = hh2, ww2
-        return h
-
-    def _shallow_up(self, h, st, tproj, text):
-        o, w = self.ops, self.w
-        F, skips, sizes = st["F"], list(st["skips"][:-1]), st["sizes"]       # the last shallow skip (down1 output) was consumed by _deep
-        B = 2 * F
-        hh, ww = sizes[1]
-        for i in (2, 3):
-            co = sd15.BLOCK_OUT[::-1][i]
-            for j in range(3):
-                sk, cs = skips.pop()
-                h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
-                h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, F, hh, ww, text)
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text)
             if i < 3:
-                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[0])
+                level -= 1
+                h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[level])   # nearest upsample fused in the gather
                 self._fl(2.0 * B * hh2 * ww2 * 9 * co * co)
                 hh, ww = hh2, ww2
         hn = o.groupnorm(h, 320, *w["norm_out"], B, hh * ww, 1e-5, True)
         eps, _, _ = o.conv3x3(hn, B, hh, ww, 320, *w["conv_out"])
         self._fl(2.0 * B * hh * ww * 9 * 320 * 4)
+        self.tome.end_forward()
         return eps
 
-    def forward_many(self, xs, Fs, Hh, Ww, t, text):
-        """xs: list of [2F_i, Hh, Ww, 8] f16 chunk inputs in the reference's chunk order; -> list of eps [2F_i, Hh, Ww, 4]."""
-        tproj = self._temb(t)
-        tome = self.tome
-        states = []
-        for x_in, F in zip(xs, Fs):
-            tome.begin_forward(F, (Hh, Ww))                      # this chunk's lock-step draws (patch.py:206-231)
-            st = self._shallow_down(x_in, F, Hh, Ww, tproj, text)
-            st["draw"] = (tome.randf, tome.coin)
-            states.append(st)
-        h2, w2 = states[0]["sizes"][2]
-        h1, w1 = states[0]["sizes"][1]
-        Ftot = sum(Fs)
-        if len(xs) == 1:
-            hd = states[0]["h"]
-        else:       # activations are [samples * pixels, C]: stack all unconditional samples, then all conditional ones
-            n2 = h2 * w2
-            hd = torch.cat([st["h"][:st["F"] * n2] for st in states] + [st["h"][st["F"] * n2:] for st in states])
-        tome.F, tome.size = Ftot, (Hh, Ww)
-        hu = self._deep(hd, Ftot, h2, w2, (h1, w1), tproj, text)
-        outs, off, n1 = [], 0, h1 * w1
-        for st in states:
-            F = st["F"]
-            hi = hu if len(xs) == 1 else torch.cat([hu[off * n1:(off + F) * n1], hu[(Ftot + off) * n1:(Ftot + off + F) * n1]])
-            off += F
-            tome.F, tome.size = F, (Hh, Ww)
-            tome.randf, tome.coin = st["draw"]
-            outs.append(self._shallow_up(hi, st, tproj, text))
-            st.clear()
-        tome.end_forward()
-        return outs
-
     def forward_nhwc(self, x_in, F, Hh, Ww, t, text):
-        """x_in [2F, Hh, Ww, 8] f16 (latents | concat_conds); text [2, L, 768] f16 (uncond, cond). -> eps [2F, Hh, Ww, 4] f16."""
-        return self.forward_many([x_in], [F], Hh, Ww, t, text)[0]
+        """One chunk: x_in [2F, Hh, Ww, 8] f16 -> eps [2F, Hh, Ww, 4] f16."""
+        return self.forward_many(x_in, [F], Hh, Ww, t, text)

@@ -43,14 +43,25 @@ class VidToMe:
         self.banks.clear()
 
     def begin_forward(self, F, size):
-        """One UNet forward: fix the draws every patched block will see (lock-step generators of the reference)."""
-        self.F, self.size = F, size
-        if self.draws is not None:
-            self.randf, self.coin = self.draws.pop(0)
-        else:
-            ts = min(self.args["target_stride"], F)
-            self.randf = int(self.rng.integers(0, ts)) if F > 1 else -1
-            self.coin = float(self.rng.random())
+        """One UNet forward over one chunk: fix the draws every patched block will see (lock-step generators of the reference)."""
+        self.begin_step([F], size)
+        self.select_chunk(0)
+
+    def begin_step(self, Fs, size):
+        """One UNet pass over the chunks Fs (reference chunk order): draw each chunk's (randf, coin) in that order."""
+        self.size = size
+        self._chunks = []
+        for F in Fs:
+            if self.draws is not None:
+                randf, coin = self.draws.pop(0)
+            else:
+                ts = min(self.args["target_stride"], F)
+                randf = int(self.rng.integers(0, ts)) if F > 1 else -1
+                coin = float(self.rng.random())
+            self._chunks.append((F, randf, coin))
+
+    def select_chunk(self, i):
+        self.F, self.randf, self.coin = self._chunks[i]
 
     def end_forward(self):
         pass
@@ -72,12 +83,17 @@ class VidToMe:
             hit = self._pos[key] = torch.arange(lo, hi, dtype=I32, device=self.dev)
         return hit
 
-    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio):
-        """tokens [2, T, C] -> (mrg [na-r+nb], unm [T]) int32 device maps."""
+    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None):
+        """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps."""
         L = self.L
         r = min(na, int(na * ratio))                                            # merge.py:90
         metric = torch.empty(2 * T, C, dtype=H16, device=self.dev)
-        L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+        if tbs is None or tbs == T * C:
+            L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+        else:
+            flat = tokens.reshape(-1)
+            L.tcl_tome_normalize_f16(flat, metric, T, C, stream())
+            L.tcl_tome_normalize_f16(flat[tbs:], metric[T:], T, C, stream())
         need = L.tcl_tome_match_workspace_bytes(na)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
@@ -87,24 +103,35 @@ class VidToMe:
         return mrg, unm, na - r + nb
 
     # ---- patch.py:14-91
-    def compute_merge(self, name, x, F, N, C, _unused=None):
-        """x: norm1 output [2F, N, C] (== joined [2, F*N, C]).  Returns None when this block is not merged, else
+    def merges(self, N):
+        """patch.py:15-18: does a block with N tokens per frame merge at all?"""
+        if not self.enabled:
+            return False
+        return int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N))) <= self.args["max_downsample"]
+
+    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None):
+        """x: norm1 output of one chunk: the unconditional [F*N, C] rows at x, the conditional ones xbs elements further (default
+        F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]).  Returns None when this block is not merged, else
         (merged [2,T,C], unm int32 [F*N] or None for identity, T)."""
         a = self.args
-        if not self.enabled:
-            return None
-        downsample = int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N)))   # patch.py:15-17
-        if downsample > a["max_downsample"]:
+        if not self.merges(N):
             return None
         L = self.L
+        if xbs is None:
+            xbs = F * N * C
         if F > 1:
             a_pos, b_pos = self._positions(F, N, self.randf)
-            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, (F - 1) * N, b_pos, N, a["local_merge_ratio"])
+            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, (F - 1) * N, b_pos, N, a["local_merge_ratio"], tbs=xbs)
             local = torch.empty(2, TL, C, dtype=H16, device=self.dev)
-            L.tcl_gather_rows_f16(x, F * N * C, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
+            L.tcl_gather_rows_f16(x, xbs, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
         else:
             mrg1 = unm1 = None
-            local, TL = x.view(2, N, C), N              # F == 1: nothing to merge locally; keep the [2, T, C] bank layout
+            TL = N                                       # F == 1: nothing to merge locally; keep the [2, T, C] layout
+            if xbs == N * C:
+                local = x.reshape(-1)[:2 * N * C].view(2, N, C)
+            else:
+                local = torch.empty(2, N, C, dtype=H16, device=self.dev)
+                L.tcl_gather_rows_f16(x, xbs, 0, 0, 0, local, N * C, 2, N, C, stream())
         if not a["merge_global"]:
             return local, unm1, TL
         bank = self.banks.get(name)

@@ -69,8 +69,8 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
  * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0; lda, ldw (row strides of A, W
  * in halves) % 8 == 0.  torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL.
- * act 2 = fused GEGLU (diffusers ff.net.0 + GEGLU): W/bias rows must be pre-arranged in 128-row groups [64 value rows | the 64
- * matching gate rows]; C is [M, N/2] = value * gelu(gate); N % 128 == 0, no resid. */
+ * act 2 = fused GEGLU (diffusers ff.net.0 + GEGLU): W/bias rows must be pre-arranged in 64-row groups [32 value rows | the 32
+ * matching gate rows]; C is [M, N/2] = value * gelu(gate); N % 64 == 0, no resid. */
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st);
 /* Register caller-owned device scratch for split-K partial sums (used by tcl_gemm_f16 / tcl_conv3x3_f16 when the tile grid

@@ -161,13 +161,14 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
             }
         }
         __syncthreads();
-        if (act == 2) {     // GEGLU (diffusers GEGLU, ff.net.0): the tile holds [a (BN/2) | gate (BN/2)] of the same output columns
+        if (act == 2) {     // GEGLU (diffusers GEGLU, ff.net.0): every 64-column group holds [32 value | 32 gate] of the same output columns
             constexpr int CPH = BN / 16;
 #pragma unroll
             for (int i = 0; i < BM * CPH / 256; ++i) {
                 const int c = tid + 256 * i, row = c / CPH, c8 = (c % CPH) * 8, m = m0 + row, n = (n0 >> 1) + c8;
                 if (m < M && n < (N >> 1)) {
-                    half8 va = *(const half8*)(Cs + row * CS + c8), vg = *(const half8*)(Cs + row * CS + BN / 2 + c8);
+                    const int gc = (c8 >> 5) * 64 + (c8 & 31);           // 64-column groups [32 value | 32 gate]
+                    half8 va = *(const half8*)(Cs + row * CS + gc), vg = *(const half8*)(Cs + row * CS + gc + 32);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
                     *(half8*)(C + (long)m * ldc + n) = va;
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
         for (int i = 0; i < BM * CPH / 256; ++i) {
             const int c = tid + 256 * i, row = c / CPH, c8 = (c % CPH) * 8, m = m0 + row, n = (n0 >> 1) + c8;
             if (m < M && n < (N >> 1)) {
-                half8 va = *(const half8*)(Cs + row * CS + c8), vg = *(const half8*)(Cs + row * CS + BN / 2 + c8);
+                const int gc = (c8 >> 5) * 64 + (c8 & 31);               // 64-column groups [32 value | 32 gate]
+                half8 va = *(const half8*)(Cs + row * CS + gc), vg = *(const half8*)(Cs + row * CS + gc + 32);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
                 *(half8*)(C + (long)m * ldc + n) = va;
@@ -512,8 +514,8 @@ static bool cfg_ok(int cfg, int M, int N, int K, int ldc, int ldr, bool has_resi
     const bool vec_ok = (N & 7) == 0 && (ldc & 7) == 0 && (!has_resid || (ldr & 7) == 0) && (K % 32) == 0;
     if (cfg == 9 || cfg == 10) return act != 2 || cfg == 9;
     if (!vec_ok) return false;
-    if (cfg >= 5 && cfg <= 8) return act != 2 && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0);
-    if (act == 2) return cfg == 1 || cfg == 2 || cfg == 11;            // GEGLU epilogue: 128-wide [value | gate] tiles
+    if (cfg >= 5 && cfg <= 8) return (act != 2 || cfg >= 7) && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0);   // GEGLU: 64-column wave strips only
+    if (act == 2) return true;                                          // GEGLU epilogue: 64-column [value | gate] groups, every BN is a multiple
     return true;
 }
 
@@ -557,7 +559,7 @@ static int heuristic_cfg(int M, int N, int K, int ldc, int ldr, bool has_resid, 
 
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    if (act == 2 && (N % 128 != 0 || (N & 15) || (ldc & 7) || resid)) return TCL_EINVAL;  // GEGLU epilogue: 128-wide [a|gate] tiles only
+    if (act == 2 && (N % 64 != 0 || (ldc & 7) || resid)) return TCL_EINVAL;      // GEGLU epilogue: 64-column [value | gate] groups
     if (g_tune_cfg) {
         if (!cfg_ok(g_tune_cfg, M, N, K, ldc, ldr, resid != nullptr, act, cp)) return TCL_EINVAL;
         return run_cfg(g_tune_cfg, g_tune_splits > 0 ? g_tune_splits : 1, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
@@ -579,8 +581,8 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     int cand[9], nc = 0;
     const int t128 = cdiv(M, 128) * cdiv(N, 128);
     cand[nc++] = 1;
-    if (t128 < 4096) { cand[nc++] = 2; if (act != 2) cand[nc++] = 3; }
-    if (t128 < 1024 && act != 2) cand[nc++] = 4;
+    if (t128 < 4096) { cand[nc++] = 2; cand[nc++] = 3; }
+    if (t128 < 1024) cand[nc++] = 4;
     if (t128 >= 256) cand[nc++] = 11;
     if (splits == 1 && K >= 512) {
         if (N % 320 == 0 && N % 256 != 0) { if (cdiv(M, 256) * (N / 320) >= 96) cand[nc++] = 5; if (cdiv(M, 128) * (N / 320) >= 96) cand[nc++] = 6; }

@@ -191,8 +191,21 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        if (act == 2) {            // GEGLU (NT == 2 only): the wave's 64 columns are one [32 value | 32 gate] group -> 32 output columns
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = lane + 64 * i, row = c >> 2, c8 = (c & 3) * 8, m = m0 + (wm * MT + a) * 32 + row, n = ((n0 + wn * WCOLS) >> 1) + c8;
+                if (m < M && n < (N >> 1)) {
+                    half8 va = *(const half8*)(Cs + row * CSW + c8), vg = *(const half8*)(Cs + row * CSW + 32 + c8);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                    *(half8*)(C + (long)m * ldc + n) = va;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 32 * CPRW / 64; ++i) {
+            if (act == 2) break;
             const int c = lane + 64 * i, row = c / CPRW, c8 = (c % CPRW) * 8, m = m0 + (wm * MT + a) * 32 + row, n = n0 + wn * WCOLS + c8;
             if (m < M && n < N) {
                 half8 v = *(const half8*)(Cs + row * CSW + c8);
@@ -228,7 +241,8 @@ static int launch8(const _Float16* A, const _Float16* W, const _Float16* bias, c
 }
 
 // cfg: 1 = 256x320 (N % 320 == 0), 2 = 128x320, 3 = 256x256 (N % 256 == 0), 4 = 128x256.  Preconditions (checked by the caller):
-// K % 64 == 0 (pairs of K steps share 128-B lines; conv: Cin % 64 == 0), N % 8 == 0, ldc % 8 == 0, (ldr % 8 == 0), act in {0, 1}.
+// K % 64 == 0 (pairs of K steps share 128-B lines; conv: Cin % 64 == 0), N % 8 == 0, ldc % 8 == 0, (ldr % 8 == 0), act in {0, 1};
+// act 2 (GEGLU, 64-column [value | gate] groups) on cfg 3 / 4 only.
 int gemm8_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     switch (cfg) {

@@ -22,9 +22,9 @@ def _dev(t, dev):
 
 
 def _geglu_rows(w):
-    """ff.net.0.proj rows [value (D) | gate (D)] -> 128-row groups [64 value | 64 matching gate] for the fused GEGLU epilogue."""
+    """ff.net.0.proj rows [value (D) | gate (D)] -> 64-row groups [32 value | 32 matching gate] for the fused GEGLU epilogue."""
     D = w.shape[0] // 2
-    idx = torch.arange(D).reshape(-1, 64)
+    idx = torch.arange(D).reshape(-1, 32)
     return w[torch.cat([idx, idx + D], dim=1).reshape(-1)]
 
 

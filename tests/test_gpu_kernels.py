@@ -319,3 +319,29 @@ def test_gemm_configs_bit_identical(L, shape):
         L.tcl_gemm_tune(0, 0)
         L.tcl_set_workspace(0, 0)
     torch.cuda.synchronize()
+
+
+def test_gemm_fused_geglu_configs(L):
+    """GEGLU epilogue (64-row [32 value | 32 gate] groups) across tile configurations, incl. the 8-wave 256x256 / 128x256 kernels."""
+    from tc_light_amd.unet import _geglu_rows
+    g = torch.Generator(device="cuda").manual_seed(12)
+    M, C = 4100, 320
+    A = torch.randn(M, C, device="cuda", generator=g).to(H)
+    W = (torch.randn(8 * C, C, device="cuda", generator=g) / C ** 0.5).to(H)
+    b = torch.randn(8 * C, device="cuda", generator=g).to(H)
+    Wg, bg = _geglu_rows(W).contiguous(), _geglu_rows(b).contiguous()
+    f = A.float() @ W.float().t() + b.float()
+    ref = f[:, :4 * C] * F.gelu(f[:, 4 * C:])
+    outs = {}
+    try:
+        for cfg in (1, 2, 3, 4, 11, 7, 8):
+            L.tcl_gemm_tune(cfg, 1)
+            out = torch.empty(M, 4 * C, device="cuda", dtype=H)
+            L.tcl_gemm_f16(A, Wg, bg, 0, out, M, 8 * C, C, C, C, 4 * C, 8 * C, 2, st())
+            outs[cfg] = out
+            assert rel(out, ref) < 2e-3, cfg
+        first = outs[1]
+        for cfg, o in outs.items():
+            assert torch.equal(o, first), cfg
+    finally:
+        L.tcl_gemm_tune(0, 0)

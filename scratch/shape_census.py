@@ -20,13 +20,14 @@ Ops.gemm, Ops.conv3x3 = gemm, conv
 sd = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
 eng = UNetEngine(sd,'cuda',VidToMe('cuda',seed=1))
 text = torch.randn(2,154,768,device='cuda').half(); text_t=torch.randn(2,77,768,device='cuda').half()
-def run(F,Hh,Ww,txt,n):
+def run(Fs,Hh,Ww,txt,n):
     for _ in range(n):
-        x = torch.randn(2*F,Hh,Ww,8,device='cuda').half()
-        eng.forward_nhwc(x,F,Hh,Ww,801.0,txt)
+        x = torch.randn(2*sum(Fs),Hh,Ww,8,device='cuda').half()
+        eng.forward_many(x,Fs,Hh,Ww,801.0,txt)
+        eng.tome.reset_global_tokens()
 # emulate a step's mix for config 2: 8 xy chunks (F=4, 90x120) w/ bank, 31 yt chunks (F=4, 30x90)
-run(4,90,120,text,2); xy=dict(calls); calls.clear()
-run(4,30,90,text_t,2); yt=dict(calls); calls.clear()
+run([2]+[4]*7,90,120,text,2); xy=dict(calls); calls.clear()
+run([4]*30,30,90,text_t,2); yt=dict(calls); calls.clear()
 Ops.gemm, Ops.conv3x3 = og, oc
 def timeit(fn,n=5):
     fn(); torch.cuda.synchronize()
@@ -43,11 +44,11 @@ def bench(key):
     Hu,Wu = up if up else (Hh,Ww); Ho=(Hu-1)//stride+1; Wo=(Wu-1)//stride+1
     y=torch.empty(B,Ho,Wo,co,device='cuda',dtype=H)
     return timeit(lambda: L.tcl_conv3x3_f16(x,w,0,0,y,B,Hh,Ww,ci,co,stride,1,up[0] if up else 0,up[1] if up else 0,0,st())), 2.0*B*Ho*Wo*9*ci*co
-for name,d,mult in (('xy',xy,8/2),('yt',yt,31/2)):
+for name,d,mult in (('xy',xy,1/2),('yt',yt,1/2)):
     rows=[]
     for k,c in d.items():
         ms,fl=bench(k); rows.append((ms*c*mult,k,c,ms,fl))
     rows.sort(reverse=True)
     tot=sum(r[0] for r in rows); totfl=sum(r[4]*r[2]*mult for r in rows)
     print(f"== {name}: per-step GEMM/conv time {tot:.1f} ms, {totfl/1e12:.1f} TFLOP -> {totfl/tot/1e9:.0f} TF/s")
-    for t,k,c,ms,fl in rows[:16]: print(f"  {t:7.1f} ms  x{int(c*mult):4d}  {ms*1e3:8.1f} us  {fl/ms/1e9:6.0f} TF/s  {k}")
+    for t,k,c,ms,fl in rows[:22]: print(f"  {t:7.1f} ms  x{int(c*mult):4d}  {ms*1e3:8.1f} us  {fl/ms/1e9:6.0f} TF/s  {k}")

@@ -1,12 +1,24 @@
-"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite output) as a text table.  usage: prof_summary.py <dir> [rows]"""
+"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite output) as a text table.
+usage: prof_summary.py <dir> [rows] [--last-pass KERNEL]
+--last-pass KERNEL: the traced command ran the workload twice (one warm-up pass that also carries the GEMM autotuner's timing
+launches, one timed pass); KERNEL is a kernel that closes a pass (stage 2's final k_gather_codebook): only kernels that start after
+the first half of its occurrences are summarised, i.e. the timed pass alone."""
 import glob
 import re
 import sqlite3
 import sys
 
-db = glob.glob(sys.argv[1] + "/*.db")[0]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+db = glob.glob(args[0] + "/*.db")[0]
+nrows = int(args[1]) if len(args) > 1 else 45
 c = sqlite3.connect(db)
-rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
+t0 = 0
+if "--last-pass" in sys.argv:
+    mark = sys.argv[sys.argv.index("--last-pass") + 1]
+    ends = [r[0] for r in c.execute("select end from kernels where name like ? order by start", (f"%{mark}%",))]
+    t0 = ends[len(ends) // 2 - 1]
+rows = c.execute("select name, count(*), sum(duration)/1e3, avg(duration)/1e3 from kernels where start > ? group by name order by 3 desc", (t0,)).fetchall()
+tot = sum(r[2] for r in rows)
 
 
 def short(n):
@@ -15,6 +27,6 @@ def short(n):
 
 
 print(f"{'kernel':102s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
-for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 45]:
-    print(f"{short(r[0]):102s} {r[1]:7d} {r[2]:12.1f} {r[3]:10.2f} {r[4]:6.2f}")
-print(f"TOTAL_us {sum(r[2] for r in rows):.1f}")
+for r in rows[:nrows]:
+    print(f"{short(r[0]):102s} {r[1]:7d} {r[2]:12.1f} {r[3]:10.2f} {100 * r[2] / tot:6.2f}")
+print(f"TOTAL_us {tot:.1f}")

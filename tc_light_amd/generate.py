@@ -26,7 +26,8 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
     guidance_scale=2.0, n_timesteps=25, chunk_size=4, chunk_ord="mix-4", local_merge_ratio=0.6, merge_global=True,
     global_merge_ratio=0.5, global_rand=0.5, align_batch=True, max_downsample=2, noise_mode="same", alpha_t=0.0,
     final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
-    lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345)
+    lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345,
+    shard_post_opt=True)     # multi-GPU only: stage 1/2 on each rank's own frame block; False = replicated on all frames
 
 
 class Generator:
@@ -149,13 +150,25 @@ class Generator:
         x = self.ddim_sample(self.init_noise.clone(), conds, conds_t, concat_conds)
         t2 = ev()
         clean_local = self.vae.decode_latents_batch(x, self.batch_size)
-        clean = d.gather_frames(clean_local, self.n_total)
+        shard = d.world > 1 and c.shard_post_opt and c.apply_opt
+        lo, hi = d.range(self.n_total)
+        if shard:
+            # Stage 1/2 on this rank's frame block as a video of its own (the reference run on the shard, like the xy bank chains):
+            # its first frame has no predecessor, tracks are cut at the block boundary (the global track ids restricted to the block
+            # and renumbered densely give the same partition as get_flowid started at the block's first frame).  No collective at all.
+            clean = clean_local
+            past_flows, mask_bwds = past_flows[lo:hi], mask_bwds[lo:hi]
+            hw = clean_local.shape[-2] * clean_local.shape[-1]
+            uniq, inv_local = torch.unique(unq_inv[lo * hw:hi * hw], return_inverse=True)
+            unq_inv, k = inv_local.to(torch.int32), int(uniq.numel())
+        else:
+            clean = d.gather_frames(clean_local, self.n_total)
         t3 = ev()
         losses1 = losses2 = None
         if c.apply_opt:
-            N = self.n_total
+            N = clean.shape[0]
             ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
-            rng = np.random.default_rng(c.seed)           # identical on every rank -> replicated stage 1/2
+            rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # replicated mode: identical schedule on every rank
             s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)
             _, _, losses1 = post_opt.exposure_align(ds, s1, c.epochs_exposure, c.batch_size, c.exposure_lr_init, c.exposure_lr_final,
                                                     c.lambda_dssim, c.lambda_flow)
@@ -166,6 +179,8 @@ class Generator:
                                                                         c.lambda_flow, c.lambda_tv, k=k)
             else:
                 clean = ds.edited_images
+            if shard:
+                clean = d.gather_frames(clean.contiguous(), self.n_total)
             t5 = ev()
         else:
             t4 = t5 = t3

@@ -34,3 +34,27 @@ def test_windows_alpha_shards(golden):
     np.testing.assert_allclose(HL.alpha_schedule(0.01, 0.01, 20), g["ddim_alphas"], rtol=1e-12)
     sizes = [HL.shard_range(300, r, 8) for r in range(8)]
     assert [b - a for a, b in sizes] == [38, 38, 38, 38, 37, 37, 37, 37] and sizes[0][0] == 0 and sizes[-1][1] == 300
+
+
+def test_shard_track_ids_equal_fresh_flowid():
+    """Multi-GPU stage 2 runs on each rank's frame block with the GLOBAL track ids restricted to the block and renumbered densely
+    (generate.py of this repo, `shard_post_opt`).  That is the partition get_flowid (flow_utils.py:56-93) gives when started at the
+    block's first frame -- i.e. the reference run on the shard."""
+    import torch
+    import synth
+    from oracle import path2 as O2
+    n, h, w = 7, 40, 56
+    d = synth.video_clip(n, h, w, seed=4)
+    frames = d["frames"].clone()
+    frames[:, :, 0, 0] = 1.0                                   # same max in every block -> same colour threshold
+    fwd = torch.zeros(n, 2, h, w)
+    fwd[:, 0], fwd[:, 1] = -1.5, -0.5                          # forward flow of the synthetic translation
+    fwd += 0.05 * torch.randn(fwd.shape, generator=torch.Generator().manual_seed(1))
+    masks = d["masks"]
+    ids = O2.get_flowid(frames, fwd, masks)
+    for lo, hi in ((0, 4), (4, 7), (2, 6)):
+        _, local = torch.unique(ids[lo:hi].reshape(-1), return_inverse=True)
+        fresh = O2.get_flowid(frames[lo:hi], fwd[lo:hi], masks[lo:hi]).reshape(-1)
+        # same partition <=> the pairing (local id, fresh id) is one-to-one
+        pairs = torch.unique(torch.stack([local, fresh], 1), dim=0)
+        assert pairs.shape[0] == local.max().item() + 1 == fresh.max().item() + 1

@@ -93,9 +93,8 @@ int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* 
 
 /* torch.nn.GroupNorm(groups, C1+C2, eps) [+ SiLU] over x = cat([x1, x2], channel) (x2 may be NULL with C2 = 0): the
  * ResnetBlock2D / Transformer2DModel / AutoencoderKL norms, with the up-block skip concat folded in.  y [B,HW,C1+C2].
- * ws: tcl_groupnorm_workspace_bytes(B, C) bytes that the caller ZEROES ONCE before the first call and then passes only to
- * tcl_groupnorm_f16 (same B and groups, one stream): each call accumulates its statistics into one of two slots and clears the
- * other for the next call, so no memset is launched per call. */
+ * ws: tcl_groupnorm_workspace_bytes(B, C) bytes of scratch (per-block partial sums).  Deterministic: no float atomics -- the same
+ * input gives the same bits on every run. */
 size_t tcl_groupnorm_workspace_bytes(int B, int C);
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st);

@@ -11,27 +11,26 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------ GroupNorm
-// pass 1: per-(batch, group) sum / sumsq.  x = [x1 | x2] concatenated on channels (x2 may be null).
+// pass 1: per-(batch, group) sum / sumsq of x = [x1 | x2] (channel concat, x2 may be null), DETERMINISTIC: no float atomics anywhere.
+// Each block reduces its row range to one partial per group -- every thread owns one 8-channel chunk (at most two groups, split at a
+// per-thread constant) and walks rows; the per-thread partials go to LDS and thread g adds up, in a fixed order, exactly the
+// entries that belong to group g -- and writes part[b][block][g]; k_gn_reduce then sums the blocks in order.
 __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
-                                                  int HW, int G, int rows_per_block, float* __restrict__ ws) {
-    __shared__ float gs[64], gq[64];
+                                                  int HW, int G, int rows_per_block, float* __restrict__ part) {
+    __shared__ float ps[256][4];
     const int b = blockIdx.y, C = C1 + C2, cpg = C / G, nchunk = C / 8;
-    if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
-    __syncthreads();
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
-    // each thread owns one 8-channel chunk (fixed groups) and walks rows: partial sums stay in registers, LDS atomics once
     const int cw = nchunk < 256 ? nchunk : 256, rp = 256 / cw;
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
-    if (tr < rp)
-        for (int c0 = 0; c0 < nchunk; c0 += cw) {
-            const int chunk = c0 + tc;
-            if (chunk >= nchunk) break;
-            // cpg >= 4 (checked on the host): an 8-channel chunk touches at most two groups, split at a per-thread constant
-            const int ch = chunk * 8, gf = ch / cpg, gl = (ch + 7) / cpg;
+    float gsum = 0.f, gsq = 0.f;                                  // group threadIdx.x (< G) of this block
+    for (int c0 = 0; c0 < nchunk; c0 += cw) {
+        const int chunk = c0 + tc;
+        float sa = 0, qa = 0, sl = 0, ql = 0;                     // all 8 channels / the part in the chunk's first group
+        if (tr < rp && chunk < nchunk) {
+            const int ch = chunk * 8, gf = ch / cpg;
             float wlo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) wlo[j] = ((ch + j) / cpg == gf) ? 1.f : 0.f;
-            float sa = 0, qa = 0, sl = 0, ql = 0;       // all 8 channels / the part in the first group
             const bool first = ch < C1;
             const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
             const int ld = first ? C1 : C2;
@@ -43,21 +42,53 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
                     sa += f; qa += f2; sl += f * wlo[j]; ql += f2 * wlo[j];
                 }
             }
-            atomicAdd(&gs[gf], sl); atomicAdd(&gq[gf], ql);
-            if (gl != gf) { atomicAdd(&gs[gl], sa - sl); atomicAdd(&gq[gl], qa - ql); }
         }
+        __syncthreads();
+        ps[threadIdx.x][0] = sl; ps[threadIdx.x][1] = ql; ps[threadIdx.x][2] = sa - sl; ps[threadIdx.x][3] = qa - ql;
+        __syncthreads();
+        if (threadIdx.x < G) {
+            // chunks that touch group g: floor(g*cpg/8) .. floor(((g+1)*cpg-1)/8), restricted to this c0 window
+            const int g = threadIdx.x, clo = max(g * cpg / 8, c0), chi = min(min(((g + 1) * cpg - 1) / 8, nchunk - 1), c0 + cw - 1);
+            for (int cc = clo; cc <= chi; ++cc) {
+                const int gf = cc * 8 / cpg;                          // first group of that chunk: its head goes to gf, its tail to gf + 1
+                for (int rr = 0; rr < rp; ++rr) {
+                    const float* e = ps[rr * cw + (cc - c0)];
+                    if (gf == g) { gsum += e[0]; gsq += e[1]; } else { gsum += e[2]; gsq += e[3]; }
+                }
+            }
+        }
+    }
+    if (threadIdx.x < G) {
+        float* o = part + (((long)b * gridDim.x + blockIdx.x) * 64 + threadIdx.x) * 2;
+        o[0] = gsum; o[1] = gsq;
+    }
+}
+// pass 1b: sums[b][g] = sum over the blocks in a fixed order: 8 interleaved partial sums per output, combined 0..7
+__global__ __launch_bounds__(1024) void k_gn_reduce(const float* __restrict__ part, int nblk, int G, float* __restrict__ sums) {
+    __shared__ float red[8][128];
+    const int b = blockIdx.x, o = threadIdx.x & 127, p = threadIdx.x >> 7;        // o = g*2 + k
+    float s = 0.f;
+    if (o < 2 * G) {
+        const float* src = part + (long)b * nblk * 128 + o;
+#pragma unroll 4
+        for (int i = p; i < nblk; i += 8) s += src[(long)i * 128];
+    }
+    red[p][o] = s;
     __syncthreads();
-    if (threadIdx.x < G) { atomicAdd(ws + ((long)b * G + threadIdx.x) * 2, gs[threadIdx.x]); atomicAdd(ws + ((long)b * G + threadIdx.x) * 2 + 1, gq[threadIdx.x]); }
+    if (p == 0 && o < 2 * G) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][o];
+        sums[(long)b * G * 2 + o] = t;
+    }
 }
 // pass 2: y = act((x - mean) * rstd * gamma + beta) with the per-(batch, group) statistics folded in per 8-channel chunk (a chunk
-// touches at most two groups); also materialises the channel concat.  Block (0, b) clears the OTHER statistics slot of this
-// batch entry, which the next GroupNorm call on the same workspace accumulates into (no memset launch between calls).
+// touches at most two groups); also materialises the channel concat.
 __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
-                                                  const float* __restrict__ sums, float* __restrict__ sums_next, const _Float16* __restrict__ gamma,
+                                                  const float* __restrict__ sums, const _Float16* __restrict__ gamma,
                                                   const _Float16* __restrict__ beta, float inv_n, float eps, int G, _Float16* __restrict__ y, int HW,
                                                   int silu) {
     const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8, cpg = C / G;
-    if (blockIdx.x == 0 && threadIdx.x < 2 * G) sums_next[(long)b * G * 2 + threadIdx.x] = 0.f;
     const long total = (long)HW * nchunk;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         long row = i / nchunk; int ch = (int)(i % nchunk) * 8;
@@ -338,24 +369,22 @@ int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, 
                        (_Float16*)y, ldo, M, Ci, Co);
     TCL_LAUNCH_RET();
 }
-// workspace: two statistics slots [B][64][2] f32 used alternately by successive calls (slot parity kept per workspace pointer)
-size_t tcl_groupnorm_workspace_bytes(int B, int C) { (void)C; return (size_t)2 * B * 64 * 2 * 4 + 256; }
+// workspace: per-block partials [B][nblk][64][2] f32, then the sums [B][64][2]
+static inline int gn_blocks_cap(int B) { int n = 2048 / B; return n < 4 ? 4 : (n > 256 ? 256 : n); }
+size_t tcl_groupnorm_workspace_bytes(int B, int C) { (void)C; return ((size_t)B * gn_blocks_cap(B) + B) * 64 * 2 * 4 + 256; }
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {
     const int C = C1 + C2;
     TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C / groups >= 4 && C1 % 8 == 0 && C2 % 8 == 0);
     TCL_CHECK_ARG(C2 == 0 || x2);
-    static std::unordered_map<void*, int> parity;           // which slot the next call on this workspace accumulates into
-    int& par = parity[ws];
-    float* cur = (float*)ws + (size_t)par * B * 64 * 2;
-    float* nxt = (float*)ws + (size_t)(par ^ 1) * B * 64 * 2;
-    par ^= 1;
-    int blocks = cdiv(HW, 64); if (blocks > 1024) blocks = 1024;
+    int blocks = cdiv(HW, 64); if (blocks > gn_blocks_cap(B)) blocks = gn_blocks_cap(B);
     int rpb = cdiv(HW, blocks); blocks = cdiv(HW, rpb);
-    hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, cur);
+    float* part = (float*)ws; float* sums = part + (size_t)B * gn_blocks_cap(B) * 64 * 2;
+    hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, part);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(B), dim3(1024), 0, st, part, blocks, groups, sums);
     long chunks = (long)HW * (C / 8);
     hipLaunchKernelGGL(k_gn_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
-                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, cur, nxt, (const _Float16*)gamma, (const _Float16*)beta,
+                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, sums, (const _Float16*)gamma, (const _Float16*)beta,
                        1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu);
     TCL_LAUNCH_RET();
 }

@@ -27,7 +27,8 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
     global_merge_ratio=0.5, global_rand=0.5, align_batch=True, max_downsample=2, noise_mode="same", alpha_t=0.0,
     final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
     lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345,
-    shard_post_opt=True)     # multi-GPU only: stage 1/2 on each rank's own frame block; False = replicated on all frames
+    shard_post_opt=True,
+    max_tokens_per_pass=1_500_000)   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split     # multi-GPU only: stage 1/2 on each rank's own frame block; False = replicated on all frames
 
 
 class Generator:
@@ -68,30 +69,45 @@ class Generator:
             raise NotImplementedError(f"Noise mode '{c.noise_mode}' is not supported.")
 
     # ------------------------------------------------------------------ one UNet evaluation with CFG
+    def _groups(self, chunks, tokens_per_frame):
+        """Consecutive chunks per UNet pass: as many as fit `max_tokens_per_pass` (activation memory); order is preserved, so every
+        block still meets the chunks in the reference order."""
+        cap = max(1, int(self.cfg.max_tokens_per_pass) // (2 * tokens_per_frame))
+        groups, cur, n = [], [], 0
+        for c in chunks:
+            if cur and n + len(c) > cap:
+                groups.append(cur); cur, n = [], 0
+            cur.append(c); n += len(c)
+        if cur:
+            groups.append(cur)
+        return groups
+
     def _unet_xy(self, x, cc, chunks, text, t, noises):
         """pred_noise on the xy chunks of one step (generate.py:220-224, 288-352): chunks = lists of local frame ids, reference order.
-        All chunks go through the UNet in one block-major pass (`forward_many`, see unet.py): one pack, one unpack."""
+        The chunks go through the UNet in block-major passes (`forward_many`, see unet.py): one pack, one unpack per pass."""
         L = self.L
-        frames = [f for c in chunks for f in c]
-        n = len(frames)
-        idx = torch.tensor(frames, dtype=I32, device=self.dev)
-        xin = torch.empty(2 * n, self.h, self.w, 8, dtype=H16, device=self.dev)
-        L.tcl_pack_latents_f16(x, cc, idx, n, 0, 0, 0, self.h, self.w, xin, stream())
-        eps = self.unet.forward_many(xin, [len(c) for c in chunks], self.h, self.w, t, text)
-        L.tcl_unpack_cfg_f16(eps, idx, n, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
+        for grp in self._groups(chunks, self.h * self.w):
+            frames = [f for c in grp for f in c]
+            n = len(frames)
+            idx = torch.tensor(frames, dtype=I32, device=self.dev)
+            xin = torch.empty(2 * n, self.h, self.w, 8, dtype=H16, device=self.dev)
+            L.tcl_pack_latents_f16(x, cc, idx, n, 0, 0, 0, self.h, self.w, xin, stream())
+            eps = self.unet.forward_many(xin, [len(c) for c in grp], self.h, self.w, t, text)
+            L.tcl_unpack_cfg_f16(eps, idx, n, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
 
     def _unet_yt(self, x_full, cc_full, items, nt_full, text_t, t):
         """pred_noise on the yt chunks of one frame window: 'n c h w -> w c n h' (generate.py:265-273); items share (start, length)."""
         L = self.L
         sl, nwin, _, scale_upto, nkeep = items[0]
-        cols = [c for it in items for c in it[2]]
-        n = len(cols)
-        idx = torch.tensor(cols, dtype=I32, device=self.dev)
-        xin = torch.empty(2 * n, nwin, self.h, 8, dtype=H16, device=self.dev)
-        L.tcl_pack_latents_f16(x_full, cc_full, idx, n, 1, sl, nwin, self.h, self.w, xin, stream())
-        eps = self.unet.forward_many(xin, [len(it[2]) for it in items], nwin, self.h, t, text_t)
-        L.tcl_unpack_cfg_f16(eps, idx, n, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
-                             nkeep, nt_full, stream())
+        for grp in self._groups([it[2] for it in items], nwin * self.h):
+            cols = [c for ch in grp for c in ch]
+            n = len(cols)
+            idx = torch.tensor(cols, dtype=I32, device=self.dev)
+            xin = torch.empty(2 * n, nwin, self.h, 8, dtype=H16, device=self.dev)
+            L.tcl_pack_latents_f16(x_full, cc_full, idx, n, 1, sl, nwin, self.h, self.w, xin, stream())
+            eps = self.unet.forward_many(xin, [len(ch) for ch in grp], nwin, self.h, t, text_t)
+            L.tcl_unpack_cfg_f16(eps, idx, n, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
+                                 nkeep, nt_full, stream())
 
     def _yt_items(self, w_chunks):
         """(window start, length, columns, scale_upto, nkeep) in the reference's loop order (generate.py:265-278)."""

@@ -110,11 +110,12 @@ def test_unet_two_chunks(setup):
 
 
 def test_forward_many_equals_sequential(setup):
-    """forward_many (all chunks in one block-major pass, only attn1 of the merging blocks chunk by chunk) against the plain per-chunk loop of the
-    reference (generate.py:220-224) with the same VidToMe draws: same bank chains per block, same chunk order.  The two schedules are
-    not bit-identical (GroupNorm statistics use float atomics; the K-split count of the deep GEMMs depends on the row count), and
-    with random weights a last-bit change can flip near-tied matches, so the yardstick is the run-to-run spread of the sequential
-    loop itself: forward_many must agree with a sequential run about as well as a second sequential run does."""
+    """forward_many (all chunks in one block-major pass, only attn1 of the merging blocks chunk by chunk) against the plain per-chunk
+    loop of the reference (generate.py:220-224) with the same VidToMe draws: same bank chains per block, same chunk order.  Every kernel is
+    deterministic (the per-chunk loop run twice is bit-identical -- asserted), but the two schedules are not bit-identical to each other: the
+    K-split count of a GEMM and the block partition of the GroupNorm sums depend on the row count, so f32 sums are associated differently,
+    and with random weights on a 16x24 latent a last-bit change flips near-tied matches.  Bounds: >= 85 % of all unmerge-map entries equal
+    on average, eps within 2e-2 rel-L2 (measured 0.91 / 0.009)."""
     sd, eng, tome = setup
     Hh, Ww, t = 16, 24, 801.0
     Fs = [1, 3, 2]
@@ -154,5 +155,5 @@ def test_forward_many_equals_sequential(setup):
     seq1, seq2, many = run(False), run(False), run(True)
     base, got = compare(seq1, seq2), compare(seq1, many)
     print("sequential vs sequential (min/mean map agreement, max eps rel-L2):", base, " sequential vs forward_many:", got)
-    assert got[1] > base[1] - 0.05            # measured: 0.76 (sequential twice) vs 0.75 on this 16x24 random-weight case
-    assert got[2] < max(2e-2, 3 * base[2])
+    assert base == (1.0, 1.0, 0.0)                # deterministic kernels: no float atomics on the UNet path
+    assert got[1] > 0.85 and got[2] < 2e-2

@@ -81,38 +81,57 @@ __device__ __forceinline__ void tome_reduce(const float16v (&acc)[2][2], int dj0
 }
 
 // keys[src] = max over (batch, dst) of (sortable(f16(score)) << 32 | ~(batch*nb + dst))
-__global__ __launch_bounds__(256) void k_tome_match(const _Float16* __restrict__ metric, long bstride, int C, const int* __restrict__ a_pos,
-                                                    int na, const int* __restrict__ b_pos, int nb, int tiles_src,
-                                                    unsigned long long* __restrict__ keys) {
+// 128 (dst) x 128 (src) score tile per block, K = C in 32-wide steps.  Operand rows are gathered by position (b_pos / a_pos) straight
+// into LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB = 16 rows x 64 B per wave instruction; no VGPR staging): 3-stage ring,
+// prefetch distance 2, counted vmcnt + one raw barrier per step; rows are unpadded, the 16-B chunk index is XOR-swizzled with
+// (row>>2)&3 on the DMA source address and on the ds_read address (conflict-free b128 reads).  48 KiB LDS -> 3 blocks per CU.
+// Blocks are XCD-aware: XCD x owns the dst tiles == x (mod 8) and walks the src tiles.
+__device__ __attribute__((aligned(16))) unsigned g_tome_zero[64];
+
+__global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restrict__ metric, long bstride, int C, const int* __restrict__ a_pos,
+                                                       int na, const int* __restrict__ b_pos, int nb, int tiles_src, int tiles_dst,
+                                                       int src_per_blk, unsigned long long* __restrict__ keys) {
+    constexpr int STAGE = 256 * 64;                     // bytes: 128 dst rows then 128 src rows, 64 B each
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16* Ds = (_Float16*)smem;            // dst tile  [2][128][MS]  (MFMA A operand: rows of S^T)
-    _Float16* Ss = Ds + 2 * 128 * MS;          // src tile  [2][128][MS]  (MFMA B operand: cols of S^T)
-    const int tsrc = blockIdx.x % tiles_src, tdst = blockIdx.x / tiles_src, bb = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int nrange = (tiles_src + src_per_blk - 1) / src_per_blk;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int srange = j % nrange, tdst = (j / nrange) * 8 + xcd, bb = blockIdx.y;
+    if (tdst >= tiles_dst) return;
+    const int ts0 = srange * src_per_blk, nts = min(src_per_blk, tiles_src - ts0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
     const _Float16* base = metric + (long)bb * bstride;
-    const int kc8 = (tid & 7) * 8;
-    const _Float16* dp[4]; const _Float16* sp[4];
+    const _Float16* zero = (const _Float16*)g_tome_zero;
+    // DMA lane roles: wave w stages pieces 2w, 2w+1 of each operand; lane -> row rr = lane>>2 of the piece, LDS chunk lane&3
+    const int rr = lane >> 2, csrc = ((lane & 3) ^ ((rr >> 2) & 3)) * 8;
+    const _Float16* dp[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = (tid >> 3) + 32 * i, dj = tdst * 128 + r, si = tsrc * 128 + r;
-        dp[i] = dj < nb ? base + (long)b_pos[dj] * C + kc8 : nullptr;
-        sp[i] = si < na ? base + (long)a_pos[si] * C + kc8 : nullptr;
+    for (int i = 0; i < 2; ++i) {
+        const int dj = tdst * 128 + (wid * 2 + i) * 16 + rr;
+        dp[i] = dj < nb ? base + (long)b_pos[dj] * C + csrc : nullptr;
     }
-    uint4 rd[4], rs[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rd[i] = dp[i] ? *(const uint4*)(dp[i] + kt * 64) : make_uint4(0, 0, 0, 0);
-            rs[i] = sp[i] ? *(const uint4*)(sp[i] + kt * 64) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint4*)(Ds + (buf * 128 + (tid >> 3) + 32 * i) * MS + kc8) = rd[i];
-            *(uint4*)(Ss + (buf * 128 + (tid >> 3) + 32 * i) * MS + kc8) = rs[i];
-        }
-    };
+    const int nk = C / 32, nstep = nts * nk, frow = lane & 31, fh = lane >> 5;
+    // One flattened loop over (src tile, k step): the DMA ring keeps running across tile boundaries, so the prologue of the next src
+    // tile and the epilogue of the current one (VALU + atomics) overlap.  The src row pointers of the tile being ISSUED live in sp.
+    const _Float16* sp[2];
+    int it_issue = -1;
+#define TOME_ISSUE(STEP, BUF)                                                                                                 \
+    {                                                                                                                         \
+        const int t_ = (STEP) / nk, kt_ = (STEP) - t_ * nk;                                                                   \
+        if (t_ != it_issue) {                                                                                                 \
+            it_issue = t_;                                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+                const int si_ = (ts0 + t_) * 128 + (wid * 2 + i) * 16 + rr;                                                   \
+                sp[i] = si_ < na ? base + (long)a_pos[si_] * C + csrc : nullptr;                                              \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        char* sb_ = smem + (BUF) * STAGE;                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                      \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp[i] ? dp[i] + kt_ * 32 : zero), \
+                                             (__attribute__((address_space(3))) void*)(sb_ + (wid * 2 + i) * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp[i] ? sp[i] + kt_ * 32 : zero), \
+                                             (__attribute__((address_space(3))) void*)(sb_ + 8192 + (wid * 2 + i) * 1024), 16, 0, 0); \
+        }                                                                                                                     \
+    }
     float16v acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -120,32 +139,45 @@ __global__ __launch_bounds__(256) void k_tome_match(const _Float16* __restrict__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nk = C / 64, frow = lane & 31, fk = (lane >> 5) * 8;
-    gload(0); sstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const _Float16* ds = Ds + (cur * 128 + wm * 64 + frow) * MS + fk;
-        const _Float16* ss = Ss + (cur * 128 + wn * 64 + frow) * MS + fk;
+    TOME_ISSUE(0, 0);
+    if (nstep > 1) TOME_ISSUE(1, 1);
+    int buf = 0, kt = 0, tcur = 0;
+    bool drained = false;          // an epilogue's atomics were issued since the last full drain: vmcnt counts are unreliable until vmcnt(0)
+    for (int step = 0; step < nstep; ++step) {
+        if (step + 1 < nstep && !drained) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // my 4 pieces of this step landed; the next stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        drained = false;
+        __builtin_amdgcn_s_barrier();
+        if (step + 2 < nstep) { const int nb_ = buf == 0 ? 2 : buf - 1; TOME_ISSUE(step + 2, nb_); }
+        const char* db = smem + buf * STAGE + (wm * 64) * 64;
+        const char* sbp = smem + buf * STAGE + 8192 + (wn * 64) * 64;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             half8 fa[2], fb[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = *(const half8*)(ds + a * 32 * MS + ks * 16);
+            for (int a = 0; a < 2; ++a) { const int R = a * 32 + frow; fa[a] = *(const half8*)(db + R * 64 + (((2 * ks + fh) ^ ((R >> 2) & 3)) << 4)); }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = *(const half8*)(ss + b * 32 * MS + ks * 16);
+            for (int b = 0; b < 2; ++b) { const int R = b * 32 + frow; fb[b] = *(const half8*)(sbp + R * 64 + (((2 * ks + fh) ^ ((R >> 2) & 3)) << 4)); }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
-        __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+        if (++kt == nk) {                      // score tile complete: reduce it to keys, start the next src tile
+            const int dj0 = tdst * 128 + wm * 64 + 4 * (lane >> 5), si0 = (ts0 + tcur) * 128 + wn * 64 + (lane & 31);
+            if (tdst * 128 + 128 > nb) tome_reduce<true>(acc, dj0, si0, nb, na, bb, lane, keys);      // wave-uniform: last dst tile only
+            else tome_reduce<false>(acc, dj0, si0, nb, na, bb, lane, keys);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            kt = 0; ++tcur; drained = true;
+        }
     }
-    const int dj0 = tdst * 128 + wm * 64 + 4 * (lane >> 5), si0 = tsrc * 128 + wn * 64 + (lane & 31);
-    if (tdst * 128 + 128 > nb) tome_reduce<true>(acc, dj0, si0, nb, na, bb, lane, keys);      // wave-uniform: last dst tile only
-    else tome_reduce<false>(acc, dj0, si0, nb, na, bb, lane, keys);
+#undef TOME_ISSUE
 }
 
 // after the sort: order[k] = src local index of rank k (descending score).  Build the maps of SURVEY 8(a) A12/A13:
@@ -221,10 +253,16 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     int* v_in = (int*)take((size_t)na * 4); int* order = (int*)take((size_t)na * 4);
     if (hipMemsetAsync(keys, 0, (size_t)na * 8, st) != hipSuccess) return TCL_ELAUNCH;
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
-    const size_t lds = (size_t)4 * 128 * MS * 2;
+    const size_t lds = (size_t)3 * 256 * 64;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(k_tome_match, dim3(ts * td, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, keys);
+    // each block keeps one dst tile and streams a run of src tiles; runs as long as possible while ~4 blocks per slot (256 CUs x 3) remain
+    int spb = (int)((long)ts * td * Bt / 3072);
+    if (spb < 1) spb = 1;
+    if (spb > 32) spb = 32;
+    const int nrange = cdiv(ts, spb);
+    hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
+                       spb, keys);
     hipLaunchKernelGGL(k_keys_to_sort, dim3(cdiv(na, 256)), dim3(256), 0, st, keys, k_in, v_in, na);
     size_t tmp = 0;
     hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, k_in, k_out, v_in, order, na, 0, 16, st);

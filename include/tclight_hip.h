@@ -181,6 +181,17 @@ int tcl_flowid(const float* frames, const float* fwd_flows, const float* masks, 
 int tcl_flash_profile_begin(int dfilter);
 int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches);
 
+/* ---- MemFlowNet correlation lookup (utils/evaluation/memflow/core/Networks/MemFlowNet/corr.py:74-120 CorrBlock,
+ * computed on demand like the reference's unused alt_cuda_corr extension -- the all-pairs volume never exists).  f32, NHWC feature maps.
+ * tcl_avgpool2_nhwc_f32: F.avg_pool2d(2, 2) (floor on odd sizes) -- builds the fmap2 pyramid level by level.
+ * tcl_corr_lookup_f32: fmap1 [B,H,W,D]; fmap2_levels / level_h / level_w: HOST arrays of num_levels (<= 4) device pointers [B,h_l,w_l,D] and
+ * their sizes; coords [B,2,H,W] (channel 0 = x, 1 = y, in fmap2 pixels of level 0); out = [B, L*(2r+1)^2, H, W] when out_nchw (the
+ * reference's layout) else [B,H,W,L*(2r+1)^2]; channel = level*(2r+1)^2 + a*(2r+1) + b with x offset a-r and y offset b-r (the
+ * reference's meshgrid(dy, dx) order), scaled by 1/sqrt(D).  D % 64 == 0, D <= 512, radius <= 5. */
+int tcl_avgpool2_nhwc_f32(const float* x, float* y, int B, int H, int W, int D, hipStream_t st);
+int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
+                        const float* coords, float* out, int B, int H, int W, int D, int radius, int out_nchw, hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,45 @@
+"""GPU: the on-demand correlation lookup (csrc/flow.hip through tc_light_amd.memflow.CorrBlock) against the outputs of the reference's
+CorrBlock (tests/golden/memflow_corr.npz) and against the CPU oracle on a larger seeded case.  f32 with a different summation order:
+3e-5 abs on values of order 1."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return "cuda"
+
+
+def test_corr_lookup_vs_reference_golden(dev):
+    from tc_light_amd.memflow import CorrBlock
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "memflow_corr.npz"))
+    for tag in ("a", "b"):
+        f1, f2, co, ref = (torch.from_numpy(G[f"{tag}_{k}"]) for k in ("f1", "f2", "coords", "out"))
+        got = CorrBlock(f1.to(dev), f2.to(dev), num_levels=4, radius=4)(co.to(dev)).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 3e-5
+
+
+def test_corr_lookup_vs_oracle_full_size(dev):
+    """1280x720 / 8 feature maps (the reference's volume would be 829 MB per pair): property + oracle on a row subset."""
+    from oracle import memflow as OM
+    from tc_light_amd.memflow import CorrBlock
+    g = torch.Generator().manual_seed(3)
+    B, D, H, W = 1, 256, 90, 160
+    f1, f2 = torch.randn(B, D, H, W, generator=g), torch.randn(B, D, H, W, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    co = torch.stack([xs, ys])[None] + 4 * torch.randn(B, 2, H, W, generator=g)
+    got = CorrBlock(f1.to(dev), f2.to(dev))(co.to(dev)).cpu()
+    ref = OM.corr_lookup(f1, f2, co)
+    assert (got - ref).abs().max().item() < 5e-5
+    # identity flow, level 0, window centre (a = b = r): <f1, f2> at the same pixel
+    c0 = torch.stack([xs, ys])[None]
+    cen = CorrBlock(f1.to(dev), f2.to(dev))(c0.to(dev))[:, 4 * 9 + 4].cpu()
+    assert (cen - (f1 * f2).sum(1) / 16.0).abs().max().item() < 5e-5

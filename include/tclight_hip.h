@@ -192,6 +192,17 @@ int tcl_avgpool2_nhwc_f32(const float* x, float* y, int B, int H, int W, int D, 
 int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
                         const float* coords, float* out, int B, int H, int W, int D, int radius, int out_nchw, hipStream_t st);
 
+/* ---- BriaRMBG-1.4 matting (briarmbg.py, generate.py:147-167).  f32 NCHW.
+ * tcl_conv3x3_direct_f32: Conv2d(k=3, padding=dilation, dilation, stride 1|2) over x = cat([x1, x2], channel) (x2 may be NULL, C2 = 0)
+ *   with w_t = weight.reshape(Cout, Cin*9).T contiguous ([Cin*9, Cout], tap index ky*3+kx), then y = conv*scale[oc] + shift[oc]
+ *   (eval BatchNorm and the conv bias folded in), optional ReLU, then + resid (REBNCONV briarmbg.py:11-25; RSU tail `hx1d + hxin`).
+ * tcl_maxpool2_ceil_f32: MaxPool2d(2, stride=2, ceil_mode=True) over BC planes.
+ * tcl_resize_bilinear_f32: F.interpolate(size=(Ho,Wo), mode="bilinear") (align_corners=False), result * mul, optional sigmoid / clamp to [0,1]. */
+int tcl_conv3x3_direct_f32(const float* x1, int C1, const float* x2, int C2, const float* w_t, const float* scale, const float* shift,
+                           const float* resid, float* y, int B, int H, int W, int Cout, int dilation, int stride, int relu, hipStream_t st);
+int tcl_maxpool2_ceil_f32(const float* x, float* y, int BC, int H, int W, hipStream_t st);
+int tcl_resize_bilinear_f32(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, float mul, int sigmoid, int clamp01, hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,7 +47,13 @@ def main(argv=None):
         raise RuntimeError("stage 1/2 need precomputed optical flow (<video>_{future,past}_flow_memflow/*.pt); flow estimation is not "
                            "part of this engine yet (SURVEY 8(f)) -- or set post_opt.apply_opt: false")
     cfg = dict(g); cfg.update(config.post_opt); cfg["seed"] = config.seed
-    gen = Generator(pipe.unet, pipe.vae, cfg, dist=d, scheduler=scheduler)
+    rmbg = background = None
+    if config.data.get("background_cond"):                     # generate.py:147-167
+        from tc_light_amd.model_utils import load_rmbg_state
+        from tc_light_amd.rmbg import RMBGEngine
+        rmbg = RMBGEngine(load_rmbg_state((config.get("models") or {}).get("rmbg")), dev)
+        background = parser.load_video(path=config.data.background_image_path)
+    gen = Generator(pipe.unet, pipe.vae, cfg, dist=d, scheduler=scheduler, rmbg=rmbg)
     for name, prompt in g.prompt.items():
         conds = encode_prompt_pair(prompt, g.negative_prompt, dev, config.get("models", {}).get("text_encoder"))
         conds_t = encode_prompt_pair(g.prompt_t, g.negative_prompt_t, dev, config.get("models", {}).get("text_encoder"))
@@ -56,7 +62,7 @@ def main(argv=None):
             from tc_light_amd.flow_ids import soft_masks_and_ids
             fut, past = flows
             masks, inv, k = soft_masks_and_ids(frames_all, fut, past, alpha=parser.alpha)
-        out, info = gen(frames_all[lo:hi], conds, conds_t, past, masks, inv, n_total=len(frame_ids), k=k)
+        out, info = gen(frames_all[lo:hi], conds, conds_t, past, masks, inv, n_total=len(frame_ids), k=k, background=background)
         if rank == 0:
             config.total_time += info["total_time"]
             config.sec_per_frame = config.total_time / len(frame_ids)

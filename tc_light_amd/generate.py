@@ -32,11 +32,11 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
 
 
 class Generator:
-    def __init__(self, unet, vae, config=None, dist=None, scheduler=None):
+    def __init__(self, unet, vae, config=None, dist=None, scheduler=None, rmbg=None):
         cfg = dict(DEFAULTS)
         cfg.update(config or {})
         self.cfg = SimpleNamespace(**cfg)
-        self.unet, self.vae = unet, vae
+        self.unet, self.vae, self.rmbg = unet, vae, rmbg
         self.dev = unet.dev
         self.L = lib()
         self.dist = dist or Dist()
@@ -50,9 +50,15 @@ class Generator:
         self.timing = {}
 
     # ------------------------------------------------------------------ data
-    def prepare_data(self, frames):
-        """frames: this rank's block [n_local,3,H,W] f32 in [0,1] on the device (generate.py:138-204)."""
+    def prepare_data(self, frames, background=None):
+        """frames: this rank's block [n_local,3,H,W] f32 in [0,1] on the device (generate.py:138-204).  background [1|n_local,3,H,W]:
+        background compositing (generate.py:147-167): alpha from BriaRMBG on the resized frames, `alpha*fg + (1-alpha)*bg`."""
         c = self.cfg
+        if background is not None:
+            if self.rmbg is None:
+                raise RuntimeError("background compositing needs an RMBGEngine (Generator(..., rmbg=...))")
+            alpha = self.rmbg.estimate_alpha(frames, self.batch_size)
+            frames = alpha * frames + (1 - alpha) * background.to(frames)
         self.frames = frames.contiguous()
         n, _, H, W = frames.shape
         self.h, self.w = H // 8, W // 8
@@ -152,7 +158,7 @@ class Generator:
         return x
 
     # ------------------------------------------------------------------ end to end
-    def __call__(self, frames, conds, conds_t, past_flows, mask_bwds, unq_inv, n_total=None, k=None):
+    def __call__(self, frames, conds, conds_t, past_flows, mask_bwds, unq_inv, n_total=None, k=None, background=None):
         """frames: local block [n_local,3,H,W]; conds / conds_t: [2,L,768] f16 (uncond, cond) text embeddings for the xy / yt
         passes (generate.py:553-555); past_flows / mask_bwds / unq_inv: stage-2 inputs for ALL frames (device).
         Returns (relit frames [N,3,H,W] f32, info dict)."""
@@ -160,7 +166,7 @@ class Generator:
         self.n_total = n_total or frames.shape[0] * d.world
         ev = lambda: (torch.cuda.synchronize(self.dev), time.perf_counter())[1]
         t0 = ev()
-        self.prepare_data(frames)
+        self.prepare_data(frames, background)
         concat_conds = self.vae.encode_imgs_batch(self.frames, self.batch_size)
         t1 = ev()
         x = self.ddim_sample(self.init_noise.clone(), conds, conds_t, concat_conds)

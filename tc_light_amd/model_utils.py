@@ -62,6 +62,16 @@ def load_vae_state(path=None, seed=2):
     return sd15.random_state_dict(shapes, seed)
 
 
+def load_rmbg_state(path=None, seed=3):
+    """briaai/RMBG-1.4 weights (`model.safetensors` / `model.pth` with the reference module's keys, generate.py:149) or seeded stand-ins."""
+    from . import rmbg
+    if path and os.path.exists(path):
+        raw = _load_safetensors(path) if path.endswith(".safetensors") else torch.load(path, map_location="cpu")
+        return {k: v for k, v in raw.items()}
+    warnings.warn("RMBG weights not found -> seeded random BriaRMBG-shaped weights (the matte is not a trained model's)")
+    return rmbg.random_state_dict(seed)
+
+
 def init_iclight(device="cuda", models=None, seed=12345):
     """-> (pipe-like namespace with .unet/.vae/.scheduler, scheduler, 'iclight')."""
     from types import SimpleNamespace

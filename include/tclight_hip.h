@@ -69,6 +69,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
  * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0; lda, ldw (row strides of A, W
  * in halves) % 8 == 0.  torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL.
+ * act: 0 none, 1 SiLU, 3 ReLU, 4 GELU (erf), applied to A.W^T + bias before the residual is added.
  * act 2 = fused GEGLU (diffusers ff.net.0 + GEGLU): W/bias rows must be pre-arranged in 64-row groups [32 value rows | the 32
  * matching gate rows]; C is [M, N/2] = value * gelu(gate); N % 64 == 0, no resid. */
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
@@ -202,6 +203,18 @@ int tcl_conv3x3_direct_f32(const float* x1, int C1, const float* x2, int C2, con
                            const float* resid, float* y, int B, int H, int W, int Cout, int dilation, int stride, int relu, hipStream_t st);
 int tcl_maxpool2_ceil_f32(const float* x, float* y, int BC, int H, int W, hipStream_t st);
 int tcl_resize_bilinear_f32(const float* x, float* y, int BC, int H, int W, int Ho, int Wo, float mul, int sigmoid, int clamp01, hipStream_t st);
+
+/* ---- MemFlowNet encoders (core/Networks/MemFlowNet/cnn.py:124-216 BasicEncoder) -- the pieces beside tcl_gemm_f16 / tcl_conv3x3_f16.
+ * tcl_conv7x7s2_c3_f16: Conv2d(3, 64, 7, stride 2, padding 3) on x [B,3,H,W] f32 NCHW -> y [B,Ho,Wo,64] f16 NHWC; w_t [147,64] f32 with
+ *   row c*49 + ky*7 + kx (an eval BatchNorm may be folded into w_t / bias), optional ReLU.
+ * tcl_instnorm_f16: InstanceNorm2d (affine=False, biased variance, eps) over [B,HW,C] f16 NHWC, optional ReLU; deterministic.
+ * tcl_add_act_f16: y = act(a + b), act 0 none / 3 ReLU / 4 GELU(erf); n elements (n % 8 == 0).
+ * tcl_subsample2_nhwc_f16: y[b][i][j] = x[b][2i][2j] (the pixel selection of a stride-2 1x1 convolution). */
+int tcl_conv7x7s2_c3_f16(const float* x, const float* w_t, const float* bias, void* y, int B, int H, int W, int relu, hipStream_t st);
+size_t tcl_instnorm_workspace_bytes(int B, int C);
+int tcl_instnorm_f16(const void* x, void* y, int B, int HW, int C, float eps, int relu, void* ws, hipStream_t st);
+int tcl_add_act_f16(const void* a, const void* b, void* y, long n, int act, hipStream_t st);
+int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -53,3 +53,28 @@ def corr_lookup(f1, f2, coords, num_levels=4, radius=4):
         w = w.permute(0, 1, 3, 2).reshape(B, H, W, n * n) / math.sqrt(D)                    # channel a*n + b
         out[:, l * n * n:(l + 1) * n * n] = w.permute(0, 3, 1, 2)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- encoders
+def _norm(sd, p, x, norm):
+    """cnn.py:17-31: BatchNorm2d in eval mode (cnet) or InstanceNorm2d without affine (fnet)."""
+    if norm == "batch":
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
+    return F.instance_norm(x, eps=1e-5)
+
+
+def _resblock(sd, p, x, norm, stride):                # cnn.py:46-54
+    y = F.relu(_norm(sd, p + "norm1.", F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], stride=stride, padding=1), norm))
+    y = F.relu(_norm(sd, p + "norm2.", F.conv2d(y, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1), norm))
+    if stride != 1:
+        x = _norm(sd, p + "norm3.", F.conv2d(x, sd[p + "downsample.0.weight"], sd[p + "downsample.0.bias"], stride=stride), norm)
+    return F.relu(x + y)
+
+
+def basic_encoder(sd, p, x, norm):
+    """BasicEncoder.forward (cnn.py:191-216), eval mode: x [B,3,H,W] -> [B,output_dim,H/8,W/8]."""
+    x = F.relu(_norm(sd, p + "norm1.", F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], stride=2, padding=3), norm))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        x = _resblock(sd, p + f"layer{li}.0.", x, norm, stride)
+        x = _resblock(sd, p + f"layer{li}.1.", x, norm, 1)
+    return F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"])

@@ -95,3 +95,149 @@ int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MemFlowNet encoders (core/Networks/MemFlowNet/cnn.py:124-216 BasicEncoder): the pieces the f16 NHWC GEMM / conv3x3 kernels do not
+// cover -- 7x7 stride-2 stem on the 3-channel image, InstanceNorm2d, add+ReLU, stride-2 pixel subsampling for the 1x1 shortcut.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// y[b][oy][ox][0..63] (NHWC f16) = act(conv7x7(stride 2, pad 3)(x NCHW f32 [B,3,H,W]) + bias); w_t [147][64] f32, index (c*49 + ky*7 + kx)
+__global__ __launch_bounds__(256) void k_conv7x7s2(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                   _Float16* __restrict__ y, int H, int W, int Ho, int Wo, int relu) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, P = Ho * Wo;
+    if (p >= P) return;
+    const int oy = p / Wo, ox = p - oy * Wo;
+    float acc[64];
+#pragma unroll
+    for (int o = 0; o < 64; ++o) acc[o] = bias[o];
+    for (int c = 0; c < 3; ++c) {
+        const float* src = x + ((long)b * 3 + c) * H * W;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = oy * 2 - 3 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int ix = ox * 2 - 3 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float v = src[(long)iy * W + ix];
+                const float* wr = wt + (c * 49 + ky * 7 + kx) * 64;
+#pragma unroll
+                for (int o = 0; o < 64; ++o) acc[o] += v * wr[o];
+            }
+        }
+    }
+    _Float16* dst = y + ((long)b * P + p) * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float a = acc[q * 8 + j]; v[j] = (_Float16)(relu ? fmaxf(a, 0.f) : a); }
+        *(h8*)(dst + q * 8) = v;
+    }
+}
+
+// InstanceNorm2d (affine=False, biased variance) statistics, deterministic: per-block partial (sum, sumsq) per channel
+__global__ __launch_bounds__(256) void k_in_stats(const _Float16* __restrict__ x, int HW, int C, int rows_per_block, float* __restrict__ part) {
+    __shared__ float ps[256][16];
+    const int b = blockIdx.y, nchunk = C / 8;                           // C <= 256 -> nchunk <= 32
+    const int tc = threadIdx.x % nchunk, tr = threadIdx.x / nchunk, rp = 256 / nchunk;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    if (tr < rp)
+        for (int row = r0 + tr; row < r1; row += rp) {
+            const h8 v = *(const h8*)(x + ((long)b * HW + row) * C + tc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps[threadIdx.x][j] = s[j]; ps[threadIdx.x][8 + j] = q[j]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {                    // output o = k*C + c (k: 0 sum, 1 sumsq): fixed-order sum over row phases
+        const int k = o / C, c = o - k * C, chunk = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int rr = 0; rr < rp; ++rr) t += ps[rr * nchunk + chunk][k * 8 + j];
+        part[(((long)b * gridDim.x + blockIdx.x) * 2 + k) * C + c] = t;
+    }
+}
+__global__ void k_in_reduce(const float* __restrict__ part, int nblk, int C, float inv_n, float eps, float* __restrict__ stat) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < nblk; ++i) { s += part[(((long)b * nblk + i) * 2 + 0) * C + c]; q += part[(((long)b * nblk + i) * 2 + 1) * C + c]; }
+    const float mean = s * inv_n, var = fmaxf(q * inv_n - mean * mean, 0.f);
+    stat[((long)b * C + c) * 2] = mean; stat[((long)b * C + c) * 2 + 1] = rsqrtf(var + eps);
+}
+__global__ void k_in_apply(const _Float16* __restrict__ x, const float* __restrict__ stat, _Float16* __restrict__ y, int HW, int C, int relu) {
+    const int b = blockIdx.y, nchunk = C / 8;
+    const long total = (long)HW * nchunk;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / nchunk; const int ch = (int)(i % nchunk) * 8;
+        const h8 v = *(const h8*)(x + ((long)b * HW + row) * C + ch);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 st = *(const float2*)(stat + ((long)b * C + ch + j) * 2);
+            float a = ((float)v[j] - st.x) * st.y;
+            o[j] = (_Float16)(relu ? fmaxf(a, 0.f) : a);
+        }
+        *(h8*)(y + ((long)b * HW + row) * C + ch) = o;
+    }
+}
+__global__ void k_add_act(const _Float16* __restrict__ a, const _Float16* __restrict__ b, _Float16* __restrict__ y, long n8, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const h8 u = *(const h8*)(a + i * 8), v = *(const h8*)(b + i * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = (float)u[j] + (float)v[j];
+            if (act == 3) t = fmaxf(t, 0.f); else if (act == 4) t = 0.5f * t * (1.f + erff(t * 0.70710678f));
+            o[j] = (_Float16)t;
+        }
+        *(h8*)(y + i * 8) = o;
+    }
+}
+__global__ void k_subsample2(const _Float16* __restrict__ x, _Float16* __restrict__ y, int B, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, nchunk = C / 8;
+    const long total = (long)B * Ho * Wo * nchunk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nchunk) * 8; long p = i / nchunk; const int xo = (int)(p % Wo); p /= Wo; const int yo = (int)(p % Ho); const long b = p / Ho;
+        *(h8*)(y + (((b * Ho + yo) * Wo + xo) * (long)C) + ch) = *(const h8*)(x + (((b * H + 2 * yo) * W + 2 * xo) * (long)C) + ch);
+    }
+}
+
+extern "C" {
+
+int tcl_conv7x7s2_c3_f16(const float* x, const float* w_t, const float* bias, void* y, int B, int H, int W, int relu, hipStream_t st) {
+    TCL_CHECK_ARG(x && w_t && bias && y && B > 0 && H > 0 && W > 0);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(k_conv7x7s2, dim3(cdiv((long)Ho * Wo, 256), B), dim3(256), 0, st, x, w_t, bias, (_Float16*)y, H, W, Ho, Wo, relu);
+    TCL_LAUNCH_RET();
+}
+
+static inline int in_blocks(int B, int HW) { int cap = 2048 / B; cap = cap < 4 ? 4 : (cap > 256 ? 256 : cap); int n = cdiv(HW, 64); return n > cap ? cap : n; }
+size_t tcl_instnorm_workspace_bytes(int B, int C) { return ((size_t)B * 256 * 2 * C + (size_t)B * C * 2) * 4 + 256; }
+int tcl_instnorm_f16(const void* x, void* y, int B, int HW, int C, float eps, int relu, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(x && y && ws && B > 0 && HW > 0 && C % 8 == 0 && C <= 256 && 256 % (C / 8) == 0);
+    int blocks = in_blocks(B, HW);
+    const int rpb = cdiv(HW, blocks); blocks = cdiv(HW, rpb);
+    float* part = (float*)ws; float* stat = part + (size_t)B * 256 * 2 * C;
+    hipLaunchKernelGGL(k_in_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x, HW, C, rpb, part);
+    hipLaunchKernelGGL(k_in_reduce, dim3(cdiv(C, 64), B), dim3(64), 0, st, part, blocks, C, 1.f / (float)HW, eps, stat);
+    const long chunks = (long)HW * (C / 8);
+    hipLaunchKernelGGL(k_in_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
+                       (const _Float16*)x, stat, (_Float16*)y, HW, C, relu);
+    TCL_LAUNCH_RET();
+}
+int tcl_add_act_f16(const void* a, const void* b, void* y, long n, int act, hipStream_t st) {
+    TCL_CHECK_ARG(a && b && y && n > 0 && n % 8 == 0 && (act == 0 || act == 3 || act == 4));
+    hipLaunchKernelGGL(k_add_act, dim3(stream_grid(n / 8, 256, 2)), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)b, (_Float16*)y, n / 8, act);
+    TCL_LAUNCH_RET();
+}
+int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, hipStream_t st) {
+    TCL_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C % 8 == 0);
+    hipLaunchKernelGGL(k_subsample2, dim3(stream_grid((long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256, 1)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, B, H, W, C);
+    TCL_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[a][b][r] + bv;
-                    if (act == 1) v = v / (1.f + __expf(-v));
+                    v = apply_act(v, act);
                     Cs[(ml + (r & 3) + 8 * (r >> 2)) * CS + nl] = (_Float16)v;
                 }
             }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
                 if (m >= M) continue;
                 if (part) { part[((long)split * M + m) * N + n] = acc[a][b][r]; continue; }   // split-K partial (f32)
                 float v = acc[a][b][r] + bv;
-                if (act == 1) v = v / (1.f + __expf(-v));                       // SiLU
+                v = apply_act(v, act);
                 if (resid) v = (float)(_Float16)v + (float)resid[(long)m * ldr + n];
                 C[(long)m * ldc + n] = (_Float16)v;
             }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[a][b][r] + bv;
-                if (act == 1) v = v / (1.f + __expf(-v));
+                v = apply_act(v, act);
                 Cs[(ml + (r & 3) + 8 * (r >> 2)) * CS + nl] = (_Float16)v;
             }
         }
@@ -456,7 +456,7 @@ __global__ void k_splitk_finalize(const float* __restrict__ part, int splits, co
         const int n = (int)(i % N); const long m = i / N;
         float v = bias ? (float)bias[n] : 0.f;
         for (int sidx = 0; sidx < splits; ++sidx) v += part[(long)sidx * total + i];
-        if (act == 1) v = v / (1.f + __expf(-v));
+        v = apply_act(v, act);
         if (resid) v += (float)resid[m * ldr + n];
         C[m * ldc + n] = (_Float16)v;
     }
@@ -615,7 +615,7 @@ int tcl_gemm_autotune(int enable) { g_autotune = enable; if (!enable) g_tune_cac
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {
-    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 2);
+    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 4);
     ConvP cp = {};
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
                     ldw, ldc, ldr, act, cp, st);

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[a][b][r] + bv[b];
-                if (act == 1) v = v / (1.f + __expf(-v));
+                v = apply_act(v, act);
                 Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSW + b * 32 + (lane & 31)] = (_Float16)v;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -7,9 +7,169 @@ GMA / SK update block and the memory read are not ported yet.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from .lib import lib, stream
+
+H16 = torch.float16
+
+
+# ------------------------------------------------------------------------------------------------ parameter shapes / seeded stand-ins
+def encoder_param_shapes(prefix, norm, output_dim=256):
+    """State-dict keys of BasicEncoder(output_dim, norm_fn) (cnn.py:124-189) under `prefix` ('fnet.' / 'cnet.')."""
+    sh = {}
+
+    def nrm(p, c):
+        if norm == "batch":
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                sh[p + k] = (c,)
+            sh[p + "num_batches_tracked"] = ()
+
+    sh[prefix + "conv1.weight"] = (64, 3, 7, 7); sh[prefix + "conv1.bias"] = (64,)
+    nrm(prefix + "norm1.", 64)
+    cin = 64
+    for li, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), 1):
+        for bi, (ci, st) in enumerate(((cin, stride), (dim, 1))):
+            p = f"{prefix}layer{li}.{bi}."
+            sh[p + "conv1.weight"] = (dim, ci, 3, 3); sh[p + "conv1.bias"] = (dim,)
+            sh[p + "conv2.weight"] = (dim, dim, 3, 3); sh[p + "conv2.bias"] = (dim,)
+            nrm(p + "norm1.", dim); nrm(p + "norm2.", dim)
+            if st != 1:
+                nrm(p + "norm3.", dim)
+                sh[p + "downsample.0.weight"] = (dim, ci, 1, 1); sh[p + "downsample.0.bias"] = (dim,)
+                nrm(p + "downsample.1.", dim)                      # the same module as norm3 (cnn.py:42-43): duplicated keys
+        cin = dim
+    sh[prefix + "conv2.weight"] = (output_dim, 128, 1, 1); sh[prefix + "conv2.bias"] = (output_dim,)
+    return sh
+
+
+def seeded_state_dict(shapes, seed):
+    """Seeded stand-in weights (no checkpoint in the image): He-scaled convs, BatchNorm statistics near identity; the duplicated
+    `downsample.1.*` entries repeat `norm3.*`."""
+    g = np.random.default_rng(seed)
+    sd = {}
+    for k, s in shapes.items():
+        if ".downsample.1." in k:
+            continue
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(1, dtype=torch.int64)
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy((0.5 + g.random(s)).astype(np.float32))
+        elif k.endswith("running_mean") or k.endswith("bias"):
+            sd[k] = torch.from_numpy((0.1 * g.standard_normal(s)).astype(np.float32))
+        elif len(s) == 1:                                                      # norm weight
+            sd[k] = torch.from_numpy((0.8 + 0.4 * g.random(s)).astype(np.float32))
+        else:
+            fan = int(np.prod(s[1:]))
+            sd[k] = torch.from_numpy((g.standard_normal(s) * (2.0 / fan) ** 0.5).astype(np.float32))
+    for k in shapes:
+        if ".downsample.1." in k:
+            sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]
+    return sd
+
+
+def _pad_to(t, dim, n):
+    if t.shape[dim] == n:
+        return t
+    shp = list(t.shape); shp[dim] = n - t.shape[dim]
+    return torch.cat([t, torch.zeros(shp, dtype=t.dtype)], dim)
+
+
+def _up64(c):
+    return (c + 63) // 64 * 64
+
+
+class EncoderEngine:
+    """BasicEncoder (cnn.py:124-216) in f16 NHWC: 7x7 stem kernel, implicit-GEMM 3x3 convs, 1x1 convs as GEMMs.  norm 'batch' (cnet):
+    eval BatchNorm folded into the conv weights / bias, ReLU in the GEMM epilogue; norm 'instance' (fnet): tcl_instnorm_f16.  Channel
+    counts are padded to multiples of 64 with zero weights (96 -> 128); padded channels stay exactly 0 through norm and ReLU."""
+
+    def __init__(self, sd, prefix, norm, device):
+        self.dev, self.norm, self.L = torch.device(device), norm, lib()
+        f = {k[len(prefix):]: v.float() for k, v in sd.items() if k.startswith(prefix) and v.dtype.is_floating_point}
+
+        def fold(wk, bk, nk):
+            w, b = f[wk], f[bk]
+            if norm == "batch":
+                s = f[nk + "weight"] / torch.sqrt(f[nk + "running_var"] + 1e-5)
+                w = w * s.view(-1, 1, 1, 1)
+                b = (b - f[nk + "running_mean"]) * s + f[nk + "bias"]
+            return w, b
+
+        w, b = fold("conv1.weight", "conv1.bias", "norm1.")
+        self.stem = (w.reshape(64, 147).t().contiguous().to(self.dev), b.contiguous().to(self.dev))
+        self.blocks = []
+        for li, stride in ((1, 1), (2, 2), (3, 2)):
+            for bi in (0, 1):
+                p = f"layer{li}.{bi}."
+                st = stride if bi == 0 else 1
+                blk = dict(stride=st)
+                for cn, nn_ in (("conv1", "norm1."), ("conv2", "norm2.")):
+                    w, b = fold(p + cn + ".weight", p + cn + ".bias", p + nn_)
+                    co, ci = _up64(w.shape[0]), _up64(w.shape[1])
+                    w = _pad_to(_pad_to(w, 0, co), 1, ci)
+                    blk[cn] = (w.permute(0, 2, 3, 1).reshape(co, 9 * ci).to(H16).contiguous().to(self.dev), _pad_to(b, 0, co).to(H16).to(self.dev), ci, co)
+                if st != 1:
+                    w, b = fold(p + "downsample.0.weight", p + "downsample.0.bias", p + "norm3.")
+                    co, ci = _up64(w.shape[0]), _up64(w.shape[1])
+                    w = _pad_to(_pad_to(w, 0, co), 1, ci)
+                    blk["down"] = (w.reshape(co, ci).to(H16).contiguous().to(self.dev), _pad_to(b, 0, co).to(H16).to(self.dev))
+                self.blocks.append(blk)
+        self.out = (f["conv2.weight"].reshape(-1, 128).to(H16).contiguous().to(self.dev), f["conv2.bias"].to(H16).to(self.dev))
+        self._ws = {}
+
+    def _inorm(self, x, B, HW, C, relu):
+        key = (B, C)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.empty(self.L.tcl_instnorm_workspace_bytes(B, C), dtype=torch.uint8, device=self.dev)
+        y = torch.empty_like(x)
+        self.L.tcl_instnorm_f16(x, y, B, HW, C, 1e-5, int(relu), ws, stream())
+        return y
+
+    def _conv3(self, x, B, H, W, spec, stride, relu):
+        w, b, ci, co = spec
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(B * Ho * Wo, co, dtype=H16, device=self.dev)
+        self.L.tcl_conv3x3_f16(x, w, b, 0, y, B, H, W, ci, co, stride, 1, 0, 0, 3 if relu else 0, stream())
+        return y, Ho, Wo
+
+    @torch.no_grad()
+    def forward(self, img):
+        """img [B,3,H,W] f32 (H, W multiples of 8) -> feature map [B*(H/8)*(W/8), 256] f16 (NHWC rows), (H/8, W/8)."""
+        L, bn = self.L, self.norm == "batch"
+        B, _, H, W = img.shape
+        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        x = torch.empty(B * h * w, 64, dtype=H16, device=self.dev)
+        L.tcl_conv7x7s2_c3_f16(img.float().contiguous(), self.stem[0], self.stem[1], x, B, H, W, int(bn), stream())
+        if not bn:
+            x = self._inorm(x, B, h * w, 64, True)
+        for blk in self.blocks:
+            st = blk["stride"]
+            y, h2, w2 = self._conv3(x, B, h, w, blk["conv1"], st, bn)
+            C = blk["conv1"][3]
+            if not bn:
+                y = self._inorm(y, B, h2 * w2, C, True)
+            y, _, _ = self._conv3(y, B, h2, w2, blk["conv2"], 1, bn)
+            if not bn:
+                y = self._inorm(y, B, h2 * w2, C, True)
+            if st != 1:
+                Cin = x.shape[1]
+                xs = torch.empty(B * h2 * w2, Cin, dtype=H16, device=self.dev)
+                L.tcl_subsample2_nhwc_f16(x, xs, B, h, w, Cin, stream())
+                wd, bd = blk["down"]
+                xd = torch.empty(B * h2 * w2, C, dtype=H16, device=self.dev)
+                L.tcl_gemm_f16(xs, wd, bd, 0, xd, B * h2 * w2, C, Cin, Cin, Cin, C, C, 0, stream())
+                x = xd if bn else self._inorm(xd, B, h2 * w2, C, False)
+            out = torch.empty_like(y)
+            L.tcl_add_act_f16(x, y, out, y.numel(), 3, stream())
+            x, h, w = out, h2, w2
+        wo, bo = self.out
+        f = torch.empty(B * h * w, wo.shape[0], dtype=H16, device=self.dev)
+        L.tcl_gemm_f16(x, wo, bo, 0, f, B * h * w, wo.shape[0], 128, 128, 128, wo.shape[0], wo.shape[0], 0, stream())
+        return f, (h, w)
+
 
 
 class CorrBlock:

@@ -43,3 +43,19 @@ def test_corr_lookup_vs_oracle_full_size(dev):
     c0 = torch.stack([xs, ys])[None]
     cen = CorrBlock(f1.to(dev), f2.to(dev))(c0.to(dev))[:, 4 * 9 + 4].cpu()
     assert (cen - (f1 * f2).sum(1) / 16.0).abs().max().item() < 5e-5
+
+
+def test_encoders_vs_reference_golden(dev):
+    """EncoderEngine (f16 NHWC, f32 accumulate) against the reference BasicEncoder outputs (f32) on the seeded weights: ~20 chained
+    convolutions with f16 activations -> rel-L2 5e-3."""
+    from tc_light_amd import memflow as MF
+    N = np.load(os.path.join(os.path.dirname(__file__), "golden", "memflow_net.npz"))
+    img = torch.from_numpy(N["img"]).to(dev)
+    for name, norm in (("fnet", "instance"), ("cnet", "batch")):
+        sd = MF.seeded_state_dict(MF.encoder_param_shapes("", norm), int(N[name + "_seed"]))
+        eng = MF.EncoderEngine(sd, "", norm, dev)
+        f, (h, w) = eng.forward(img)
+        got = f.view(2, h, w, 256).permute(0, 3, 1, 2).float().cpu()
+        ref = torch.from_numpy(N[name])
+        assert got.shape == ref.shape
+        assert ((got - ref).norm() / ref.norm()).item() < 5e-3, name

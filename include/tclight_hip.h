@@ -69,7 +69,8 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
  * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + resid[M,N];  act: 0 none, 1 SiLU.  K % 64 == 0; lda, ldw (row strides of A, W
  * in halves) % 8 == 0.  torch.nn.Linear / 1x1 Conv2d.  bias / resid may be NULL.
- * act: 0 none, 1 SiLU, 3 ReLU, 4 GELU (erf), applied to A.W^T + bias before the residual is added.
+ * act: 0 none, 1 SiLU, 3 ReLU, 4 GELU (erf), applied to A.W^T + bias before the residual is added; 5 = GELU applied AFTER the residual
+ * add (C = gelu(A.W^T + bias + resid), resid required).
  * act 2 = fused GEGLU (diffusers ff.net.0 + GEGLU): W/bias rows must be pre-arranged in 64-row groups [32 value rows | the 32
  * matching gate rows]; C is [M, N/2] = value * gelu(gate); N % 64 == 0, no resid. */
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
@@ -190,6 +191,9 @@ int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches)
  * reference's layout) else [B,H,W,L*(2r+1)^2]; channel = level*(2r+1)^2 + a*(2r+1) + b with x offset a-r and y offset b-r (the
  * reference's meshgrid(dy, dx) order), scaled by 1/sqrt(D).  D % 64 == 0, D <= 512, radius <= 5. */
 int tcl_avgpool2_nhwc_f32(const float* x, float* y, int B, int H, int W, int D, hipStream_t st);
+/* as tcl_corr_lookup_f32, written as f16 rows [B*H*W, ld] (channels [0, L*(2r+1)^2), ld >= that; padding channels are left untouched) */
+int tcl_corr_lookup_rows_f16(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
+                             const float* coords, void* out_rows, int ld, int B, int H, int W, int D, int radius, hipStream_t st);
 int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
                         const float* coords, float* out, int B, int H, int W, int D, int radius, int out_nchw, hipStream_t st);
 
@@ -215,6 +219,18 @@ size_t tcl_instnorm_workspace_bytes(int B, int C);
 int tcl_instnorm_f16(const void* x, void* y, int B, int HW, int C, float eps, int relu, void* ws, hipStream_t st);
 int tcl_add_act_f16(const void* a, const void* b, void* y, long n, int act, hipStream_t st);
 int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, hipStream_t st);
+
+/* ---- MemFlowNet update block (core/Networks/MemFlowNet/sk2.py, MemFlow.py:172-183) -- glue beside the GEMMs, f16 NHWC rows unless noted.
+ * tcl_dwconv_gelu_f16: y = gelu(x + depthwise_kxk(x) + bias) (PCBlock4_Deep_nopool_res, sk2.py:26-27); w [k*k, C] f16 (tap-major), k odd.
+ * tcl_nchw_f32_to_rows_f16 / tcl_rows_f16_to_nchw_f32: move Cs channels between an f32 NCHW tensor [B,Cs,P] and channels [c0, c0+Cs) of f16
+ *   rows [B*P, ld] (zero_rest clears the other channels; the reverse computes out = alpha*out + beta*value, alpha 0 = overwrite).
+ * tcl_axpy_f16: y = a + s*b.   tcl_upsample_flow_f32: MemFlowNet.upsample_flow -- softmax over the 9 taps of mask_scale*mask (rows
+ *   [B*h*w, ldm], channel tap*64 + i*8 + j) applied to the 3x3 neighbourhood of 8*flow [B,2,h,w] -> [B,2,8h,8w]. */
+int tcl_dwconv_gelu_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int C, int k, hipStream_t st);
+int tcl_nchw_f32_to_rows_f16(const float* x, void* y, int B, int Cs, int P, int ld, int c0, int zero_rest, hipStream_t st);
+int tcl_rows_f16_to_nchw_f32(const void* x, float* y, int B, int Cs, int P, int ld, int c0, float alpha, float beta, hipStream_t st);
+int tcl_axpy_f16(const void* a, const void* b, float s, void* y, long n, hipStream_t st);
+int tcl_upsample_flow_f32(const float* flow, const void* mask, int ldm, float mask_scale, float* up, int B, int h, int w, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -78,3 +78,102 @@ def basic_encoder(sd, p, x, norm):
         x = _resblock(sd, p + f"layer{li}.0.", x, norm, stride)
         x = _resblock(sd, p + f"layer{li}.1.", x, norm, 1)
     return F.conv2d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"])
+
+
+# ---------------------------------------------------------------------------------------------------------------- update block
+def pcblock(sd, p, x, k_conv):
+    """PCBlock4_Deep_nopool_res.forward (sk2.py:24-30)."""
+    def ffn(q, t):
+        t = F.gelu(F.conv2d(t, sd[q + "0.weight"], sd[q + "0.bias"]))
+        return F.conv2d(t, sd[q + "2.weight"], sd[q + "2.bias"])
+    x = F.gelu(x + ffn(p + "ffn1.", x))
+    for i, k in enumerate(k_conv):
+        x = F.gelu(x + F.conv2d(x, sd[p + f"conv_list.{i}.weight"], sd[p + f"conv_list.{i}.bias"], padding=k // 2, groups=x.shape[1]))
+    x = F.gelu(x + F.conv2d(x, sd[p + "pw.weight"], sd[p + "pw.bias"]))
+    return ffn(p + "ffn2.", x)
+
+
+K_CONV, K_GRU = (1, 15), (1, 7)            # sk2.py:201-202
+
+
+def motion_and_value(sd, p, flow, corr):
+    """SKUpdateBlock6_..._Mem_skflow.get_motion_and_value (sk2.py:216-219) with its encoder (sk2.py:112-128); p = 'update_block.'."""
+    e = p + "encoder."
+    cor = pcblock(sd, e + "convc2.", F.gelu(pcblock(sd, e + "convc1.", corr, K_CONV)), K_CONV)
+    flo = pcblock(sd, e + "convf2.", F.conv2d(flow, sd[e + "convf1.weight"], sd[e + "convf1.bias"]), K_CONV)
+    out = pcblock(sd, e + "conv.", torch.cat([cor, flo], 1), K_CONV)
+    mf = torch.cat([out, flow], 1)
+    return mf, F.conv2d(mf, sd[p + "aggregator.to_v.weight"])
+
+
+def update(sd, p, net, inp, mf, mfg):
+    """SKUpdateBlock6_..._Mem_skflow.forward (sk2.py:221-229) -> (net, 0.25*mask, delta_flow)."""
+    net = pcblock(sd, p + "gru.", torch.cat([net, inp, mf, mfg], 1), K_GRU)
+    delta = pcblock(sd, p + "flow_head.", net, K_CONV)
+    m = F.conv2d(F.relu(F.conv2d(net, sd[p + "mask.0.weight"], sd[p + "mask.0.bias"], padding=1)), sd[p + "mask.2.weight"], sd[p + "mask.2.bias"])
+    return net, 0.25 * m, delta
+
+
+def encode_context(sd, img):
+    """MemFlowNet.encode_context (MemFlow.py:96-128) for one frame: -> query, key, net, inp  [B,128,h,w] each."""
+    c = basic_encoder(sd, "cnet.", img, "batch")
+    net, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
+    q, k = F.conv2d(inp, sd["att.to_qk.weight"]).chunk(2, dim=1)
+    return q, k, net, inp
+
+
+def memory_read(query, mem_key, mem_value, scale, train_avg_length):
+    """MemoryManager.match_memory without flash-attn (memory_manager_skflow.py:41-88): softmax over the memory axis of
+    <query, key> * scale * log(T, train_avg_length); keys/values [B,C,T] (working memory followed by the current frame's)."""
+    B, C, h, w = query.shape
+    q = query.flatten(2)
+    s = scale * math.log(mem_key.shape[-1], train_avg_length)
+    sim = torch.einsum("bcl,bct->btl", q, mem_key) * s
+    aff = torch.softmax(sim, dim=1)
+    return (mem_value @ aff).view(B, -1, h, w)
+
+
+def upsample_flow(flow, mask):
+    """MemFlowNet.upsample_flow (MemFlow.py:172-183)."""
+    N, _, H, W = flow.shape
+    mask = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(N, 2, 8 * H, 8 * W)
+
+
+class InferenceCore:
+    """inference/inference_core_skflow.py:6-54 + MemoryManager (memory_manager_skflow.py) for the things_memflownet configuration
+    (mem_every 1, no long-term memory, max / min mid-term frames 2 / 1, decoder depth `iters`)."""
+
+    def __init__(self, sd, iters=15, train_avg_length=(400 * 720 // 64) * 3 / 2, max_mt=2, min_mt=1):
+        self.sd, self.iters, self.tal, self.max_mt, self.min_mt = sd, iters, train_avg_length, max_mt, min_mt
+        self.mk = self.mv = None
+
+    def step(self, images, end=False, flow_init=None):
+        """images [1,2,3,H,W] in [-1,1] -> (flow_low [1,2,H/8,W/8], flow_up [1,2,H,W])."""
+        sd = self.sd
+        query, key, net, inp = encode_context(sd, images[:, 0])
+        fm = basic_encoder(sd, "fnet.", images.flatten(0, 1), "instance").float()
+        f1, f2 = fm[0:1], fm[1:2]
+        B, _, h, w = f1.shape
+        ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        coords0 = torch.stack([xs, ys])[None]
+        coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
+        scale = 128 ** -0.5
+        gamma = sd["update_block.aggregator.gamma"]
+        for _ in range(self.iters):
+            corr = corr_lookup(f1, f2, coords1)
+            mf, val = motion_and_value(sd, "update_block.", coords1 - coords0, corr)
+            k_all = key.flatten(2) if self.mk is None else torch.cat([self.mk, key.flatten(2)], -1)
+            v_all = val.flatten(2) if self.mv is None else torch.cat([self.mv, val.flatten(2)], -1)
+            mfg = mf + gamma * memory_read(query, k_all, v_all, scale, self.tal)
+            net, mask, delta = update(sd, "update_block.", net, inp, mf, mfg)
+            coords1 = coords1 + delta
+        flow_up = upsample_flow(coords1 - coords0, mask)
+        if not end:                                            # mem_every = 1: every frame is a memory frame
+            self.mk = key.flatten(2) if self.mk is None else torch.cat([self.mk, key.flatten(2)], -1)
+            self.mv = val.flatten(2) if self.mv is None else torch.cat([self.mv, val.flatten(2)], -1)
+            if self.mk.shape[-1] >= self.max_mt * h * w:       # compress_features: keep the last min_mt frames
+                self.mk, self.mv = self.mk[:, :, -self.min_mt * h * w:], self.mv[:, :, -self.min_mt * h * w:]
+        return coords1 - coords0, flow_up

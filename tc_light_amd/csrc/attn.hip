@@ -319,7 +319,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
                       long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv,
                       hipStream_t st) {
     TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
-    TCL_CHECK_ARG(d == 40 || d == 80 || d == 160);
+    TCL_CHECK_ARG(d == 40 || d == 80 || d == 128 || d == 160);
     TCL_CHECK_ARG(!pack_kv || (k && v));
     const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
@@ -339,6 +339,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (d == 40) return qb2 ? launch_flash<40, 48, 64, 2, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
                             : launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
 }
 

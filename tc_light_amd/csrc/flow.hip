@@ -21,7 +21,8 @@ __global__ void k_avgpool2_nhwc(const float* __restrict__ x, float* __restrict__
 struct CorrLevels { const float* f2[4]; int H[4], W[4]; };
 
 // out[b][(l*n + a)*n + b2] at pixel (y,x): x offset a - r, y offset b2 - r (the reference's meshgrid(dy, dx) order), * 1/sqrt(D)
-__global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f1, CorrLevels lv, const float* __restrict__ coords, float* __restrict__ out,
+template <typename OT>
+__global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f1, CorrLevels lv, const float* __restrict__ coords, OT* __restrict__ out,
                                                      int B, int H, int W, int D, int r, long out_cs, long out_ps, long out_bs, float inv_sqrt_d) {
     __shared__ float part[4][32][65];
     __shared__ float dots[4][144];
@@ -63,12 +64,12 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
         __syncthreads();
     }
     if (!live) return;
-    float* o = out + (long)b * out_bs + (long)pix * out_ps + (long)l * n * n * out_cs;
+    OT* o = out + (long)b * out_bs + (long)pix * out_ps + (long)l * n * n * out_cs;
     for (int idx = lane; idx < n * n; idx += 64) {
         const int a = idx / n, b2 = idx % n;                            // a: x offset, b2: y offset
         const float* d0 = &dots[wid][b2 * n1 + a];
         const float v = (1.f - fx) * (1.f - fy) * d0[0] + fx * (1.f - fy) * d0[1] + (1.f - fx) * fy * d0[n1] + fx * fy * d0[n1 + 1];
-        o[(long)idx * out_cs] = v * inv_sqrt_d;
+        o[(long)idx * out_cs] = (OT)(v * inv_sqrt_d);
     }
 }
 
@@ -89,8 +90,24 @@ int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, co
     for (int i = 0; i < num_levels; ++i) TCL_CHECK_ARG(lv.f2[i] && lv.H[i] > 0 && lv.W[i] > 0);
     const int n = 2 * radius + 1, P = H * W, C = num_levels * n * n;
     const long cs = out_nchw ? P : 1, ps = out_nchw ? 1 : C, bs = (long)C * P;
-    hipLaunchKernelGGL(k_corr_lookup, dim3(cdiv(P, 4), num_levels, B), dim3(256), 0, st, fmap1, lv, coords, out, B, H, W, D, radius, cs, ps, bs,
+    hipLaunchKernelGGL(k_corr_lookup<float>, dim3(cdiv(P, 4), num_levels, B), dim3(256), 0, st, fmap1, lv, coords, out, B, H, W, D, radius, cs, ps, bs,
                        1.f / sqrtf((float)D));
+    TCL_LAUNCH_RET();
+}
+
+// same lookup written as f16 rows [B*H*W, ld] (channels [0, L*(2r+1)^2); the caller keeps the padding channels zero) -- the layout the
+// motion encoder's first 1x1 convolution (a GEMM) reads
+int tcl_corr_lookup_rows_f16(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
+                             const float* coords, void* out_rows, int ld, int B, int H, int W, int D, int radius, hipStream_t st) {
+    TCL_CHECK_ARG(fmap1 && fmap2_levels && level_h && level_w && coords && out_rows && B > 0 && H > 0 && W > 0);
+    TCL_CHECK_ARG(num_levels >= 1 && num_levels <= 4 && radius >= 1 && radius <= 5 && D % 64 == 0 && D <= 512);
+    const int n = 2 * radius + 1, P = H * W, C = num_levels * n * n;
+    TCL_CHECK_ARG(ld >= C);
+    CorrLevels lv;
+    for (int i = 0; i < 4; ++i) { lv.f2[i] = i < num_levels ? fmap2_levels[i] : nullptr; lv.H[i] = i < num_levels ? level_h[i] : 0; lv.W[i] = i < num_levels ? level_w[i] : 0; }
+    for (int i = 0; i < num_levels; ++i) TCL_CHECK_ARG(lv.f2[i] && lv.H[i] > 0 && lv.W[i] > 0);
+    hipLaunchKernelGGL(k_corr_lookup<_Float16>, dim3(cdiv(P, 4), num_levels, B), dim3(256), 0, st, fmap1, lv, coords, (_Float16*)out_rows, B, H, W, D, radius,
+                       (long)1, (long)ld, (long)P * ld, 1.f / sqrtf((float)D));
     TCL_LAUNCH_RET();
 }
 
@@ -237,6 +254,129 @@ int tcl_add_act_f16(const void* a, const void* b, void* y, long n, int act, hipS
 int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, hipStream_t st) {
     TCL_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C % 8 == 0);
     hipLaunchKernelGGL(k_subsample2, dim3(stream_grid((long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256, 1)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, B, H, W, C);
+    TCL_LAUNCH_RET();
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MemFlowNet update block (core/Networks/MemFlowNet/sk2.py): depthwise large-kernel convolution of PCBlock4_Deep_nopool_res fused with
+// its residual and GELU, and the small f32 <-> padded-f16 glue around the GEMMs.
+
+// y = gelu(x + depthwise_kxk(x) + bias)  (sk2.py:26-27: `x = F.gelu(x + conv(x))`); x, y [B,H,W,C] f16 NHWC, w [k*k][C] f16, k odd
+__global__ __launch_bounds__(256) void k_dwconv_gelu(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+                                                     _Float16* __restrict__ y, int H, int W, int C, int k) {
+    const int b = blockIdx.z, ch = blockIdx.y * 8, p = blockIdx.x * 256 + threadIdx.x, P = H * W;
+    if (p >= P) return;
+    const int oy = p / W, ox = p - oy * W, r = k >> 1;
+    float acc[8];
+    const h8 bv = *(const h8*)(bias + ch);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (float)bv[j];
+    const _Float16* xb = x + (long)b * P * C + ch;
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy - r + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = ox - r + kx;
+            if (ix < 0 || ix >= W) continue;
+            const h8 v = *(const h8*)(xb + ((long)iy * W + ix) * C);
+            const h8 wv = *(const h8*)(w + (long)(ky * k + kx) * C + ch);        // block-uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * (float)wv[j];
+        }
+    }
+    const h8 xc = *(const h8*)(xb + (long)p * C);
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = (float)xc[j] + acc[j]; o[j] = (_Float16)(0.5f * t * (1.f + erff(t * 0.70710678f))); }
+    *(h8*)(y + ((long)b * P + p) * C + ch) = o;
+}
+
+// f32 NCHW [B,Cs,H,W] -> f16 NHWC rows [B*H*W, ld] channels [c0, c0+Cs) (other channels untouched unless zero_rest)
+__global__ void k_nchw_f32_to_rows_f16(const float* __restrict__ x, _Float16* __restrict__ y, int B, int Cs, int P, int ld, int c0, int zero_rest) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / P; const int p = (int)(i % P);
+        _Float16* row = y + i * ld;
+        if (zero_rest) for (int c = 0; c < ld; ++c) row[c] = (_Float16)0.f;
+        for (int c = 0; c < Cs; ++c) row[c0 + c] = (_Float16)x[(b * Cs + c) * P + p];
+    }
+}
+// f16 NHWC rows [B*P, ld] channels [c0, c0+Cs) -> f32 NCHW, out = alpha*out + beta*value
+__global__ void k_rows_f16_to_nchw_f32(const _Float16* __restrict__ x, float* __restrict__ y, int B, int Cs, int P, int ld, int c0, float alpha, float beta) {
+    const long total = (long)B * Cs * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P); long t = i / P; const int c = (int)(t % Cs); const long b = t / Cs;
+        const float v = (float)x[(b * P + p) * ld + c0 + c];
+        y[i] = (alpha != 0.f ? alpha * y[i] : 0.f) + beta * v;
+    }
+}
+// y = a + s*b (f16)
+__global__ void k_axpy_f16(const _Float16* __restrict__ a, const _Float16* __restrict__ b, float s, _Float16* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const h8 u = *(const h8*)(a + i * 8), v = *(const h8*)(b + i * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)u[j] + s * (float)v[j]);
+        *(h8*)(y + i * 8) = o;
+    }
+}
+// MemFlowNet.upsample_flow (MemFlow.py:172-183): convex combination of the 3x3 neighbourhood of 8*flow with softmax(mask) weights.
+// flow [B,2,h,w] f32, mask rows [B*h*w, ldm] f16 with channel (k*64 + i*8 + j) (k: 3x3 tap, (i,j): sub-pixel), mask_scale 0.25 -> up [B,2,8h,8w]
+__global__ void k_upsample_flow(const float* __restrict__ flow, const _Float16* __restrict__ mask, int ldm, float mask_scale, float* __restrict__ up,
+                                int B, int h, int w) {
+    const long total = (long)B * h * w * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int sub = (int)(i & 63); long p = i >> 6; const int x = (int)(p % w); p /= w; const int y = (int)(p % h); const long b = p / h;
+        const _Float16* m = mask + ((b * h + y) * w + x) * (long)ldm + sub;
+        float e[9], mx = -1e30f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { e[k] = mask_scale * (float)m[k * 64]; mx = fmaxf(mx, e[k]); }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { e[k] = __expf(e[k] - mx); s += e[k]; }
+        float fx = 0.f, fy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;         // F.unfold zero padding
+            fx += e[k] * flow[((b * 2 + 0) * h + yy) * w + xx];
+            fy += e[k] * flow[((b * 2 + 1) * h + yy) * w + xx];
+        }
+        const int si = sub >> 3, sj = sub & 7;
+        const long o = ((long)(y * 8 + si)) * (w * 8) + x * 8 + sj;
+        up[(b * 2 + 0) * (long)(h * 8) * (w * 8) + o] = 8.f * fx / s;
+        up[(b * 2 + 1) * (long)(h * 8) * (w * 8) + o] = 8.f * fy / s;
+    }
+}
+
+extern "C" {
+
+int tcl_dwconv_gelu_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int C, int k, hipStream_t st) {
+    TCL_CHECK_ARG(x && w && bias && y && B > 0 && H > 0 && W > 0 && C % 8 == 0 && k >= 1 && (k & 1));
+    hipLaunchKernelGGL(k_dwconv_gelu, dim3(cdiv((long)H * W, 256), C / 8, B), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
+                       (_Float16*)y, H, W, C, k);
+    TCL_LAUNCH_RET();
+}
+int tcl_nchw_f32_to_rows_f16(const float* x, void* y, int B, int Cs, int P, int ld, int c0, int zero_rest, hipStream_t st) {
+    TCL_CHECK_ARG(x && y && B > 0 && Cs > 0 && P > 0 && c0 >= 0 && c0 + Cs <= ld);
+    hipLaunchKernelGGL(k_nchw_f32_to_rows_f16, dim3(stream_grid((long)B * P, 256, 1)), dim3(256), 0, st, x, (_Float16*)y, B, Cs, P, ld, c0, zero_rest);
+    TCL_LAUNCH_RET();
+}
+int tcl_rows_f16_to_nchw_f32(const void* x, float* y, int B, int Cs, int P, int ld, int c0, float alpha, float beta, hipStream_t st) {
+    TCL_CHECK_ARG(x && y && B > 0 && Cs > 0 && P > 0 && c0 >= 0 && c0 + Cs <= ld);
+    hipLaunchKernelGGL(k_rows_f16_to_nchw_f32, dim3(stream_grid((long)B * Cs * P, 256, 1)), dim3(256), 0, st, (const _Float16*)x, y, B, Cs, P, ld, c0, alpha, beta);
+    TCL_LAUNCH_RET();
+}
+int tcl_axpy_f16(const void* a, const void* b, float s, void* y, long n, hipStream_t st) {
+    TCL_CHECK_ARG(a && b && y && n > 0 && n % 8 == 0);
+    hipLaunchKernelGGL(k_axpy_f16, dim3(stream_grid(n / 8, 256, 2)), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)b, s, (_Float16*)y, n / 8);
+    TCL_LAUNCH_RET();
+}
+int tcl_upsample_flow_f32(const float* flow, const void* mask, int ldm, float mask_scale, float* up, int B, int h, int w, hipStream_t st) {
+    TCL_CHECK_ARG(flow && mask && up && B > 0 && h > 0 && w > 0 && ldm >= 576);
+    hipLaunchKernelGGL(k_upsample_flow, dim3(stream_grid((long)B * h * w * 64, 256, 1)), dim3(256), 0, st, flow, (const _Float16*)mask, ldm, mask_scale, up, B, h, w);
     TCL_LAUNCH_RET();
 }
 

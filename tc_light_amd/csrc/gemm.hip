@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
                 if (resid) {
                     half8 rv = *(const half8*)(resid + (long)m * ldr + n);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] + (float)rv[q]);
+                    for (int q = 0; q < 8; ++q) v[q] = (_Float16)post_act((float)v[q] + (float)rv[q], act);
                 }
                 *(half8*)(C + (long)m * ldc + n) = v;
             }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
                 if (part) { part[((long)split * M + m) * N + n] = acc[a][b][r]; continue; }   // split-K partial (f32)
                 float v = acc[a][b][r] + bv;
                 v = apply_act(v, act);
-                if (resid) v = (float)(_Float16)v + (float)resid[(long)m * ldr + n];
+                if (resid) v = post_act((float)(_Float16)v + (float)resid[(long)m * ldr + n], act);
                 C[(long)m * ldc + n] = (_Float16)v;
             }
         }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
             if (resid) {
                 half8 rv = *(const half8*)(resid + (long)m * ldr + n);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] + (float)rv[q]);
+                for (int q = 0; q < 8; ++q) v[q] = (_Float16)post_act((float)v[q] + (float)rv[q], act);
             }
             *(half8*)(C + (long)m * ldc + n) = v;
         }
@@ -457,7 +457,7 @@ __global__ void k_splitk_finalize(const float* __restrict__ part, int splits, co
         float v = bias ? (float)bias[n] : 0.f;
         for (int sidx = 0; sidx < splits; ++sidx) v += part[(long)sidx * total + i];
         v = apply_act(v, act);
-        if (resid) v += (float)resid[m * ldr + n];
+        if (resid) v = post_act(v + (float)resid[m * ldr + n], act);
         C[m * ldc + n] = (_Float16)v;
     }
 }
@@ -615,7 +615,7 @@ int tcl_gemm_autotune(int enable) { g_autotune = enable; if (!enable) g_tune_cac
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {
-    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 4);
+    TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 5);
     ConvP cp = {};
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
                     ldw, ldc, ldr, act, cp, st);

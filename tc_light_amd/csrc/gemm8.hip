@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
                 if (resid) {
                     half8 rv = *(const half8*)(resid + (long)m * ldr + n);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] + (float)rv[q]);
+                    for (int q = 0; q < 8; ++q) v[q] = (_Float16)post_act((float)v[q] + (float)rv[q], act);
                 }
                 *(half8*)(C + (long)m * ldc + n) = v;
             }

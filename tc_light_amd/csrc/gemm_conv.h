@@ -10,13 +10,16 @@ struct ConvP {
     float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
 };
 
-// epilogue activations: 1 SiLU, 3 ReLU, 4 GELU (erf); 0 and 2 (GEGLU, applied on column pairs by the caller) leave v unchanged
+// epilogue activations: 1 SiLU, 3 ReLU, 4 GELU (erf); 0, 2 (GEGLU, applied on column pairs by the caller) and 5 (GELU applied AFTER the
+// residual add, see post_act) leave v unchanged
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return v / (1.f + __expf(-v));
     if (act == 3) return fmaxf(v, 0.f);
     if (act == 4) return 0.5f * v * (1.f + erff(v * 0.70710678f));
     return v;
 }
+
+__device__ __forceinline__ float post_act(float v, int act) { return act == 5 ? 0.5f * v * (1.f + erff(v * 0.70710678f)) : v; }
 
 int gemm8_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st);

@@ -44,6 +44,45 @@ def encoder_param_shapes(prefix, norm, output_dim=256):
     return sh
 
 
+def pcblock_param_shapes(p, cin, cout, k_conv):
+    """PCBlock4_Deep_nopool_res(C_in, C_out, k_conv) (sk2.py:6-22)."""
+    mid = int(1.5 * cin)
+    sh = {}
+    for i, k in enumerate(k_conv):
+        sh[p + f"conv_list.{i}.weight"] = (cin, 1, k, k); sh[p + f"conv_list.{i}.bias"] = (cin,)
+    sh[p + "ffn1.0.weight"] = (mid, cin, 1, 1); sh[p + "ffn1.0.bias"] = (mid,)
+    sh[p + "ffn1.2.weight"] = (cin, mid, 1, 1); sh[p + "ffn1.2.bias"] = (cin,)
+    sh[p + "pw.weight"] = (cin, cin, 1, 1); sh[p + "pw.bias"] = (cin,)
+    sh[p + "ffn2.0.weight"] = (mid, cin, 1, 1); sh[p + "ffn2.0.bias"] = (mid,)
+    sh[p + "ffn2.2.weight"] = (cout, mid, 1, 1); sh[p + "ffn2.2.bias"] = (cout,)
+    return sh
+
+
+K_CONV, K_GRU = (1, 15), (1, 7)                                  # sk2.py:201-202
+
+
+def memflow_param_shapes():
+    """State-dict keys of MemFlowNet(cfg = things_memflownet: basicencoder cnet/fnet, GMA-SK2) (MemFlow.py:21-64)."""
+    sh = {}
+    sh.update(encoder_param_shapes("cnet.", "batch"))
+    sh.update(encoder_param_shapes("fnet.", "instance"))
+    u = "update_block."
+    sh.update(pcblock_param_shapes(u + "encoder.convc1.", 324, 256, K_CONV))
+    sh.update(pcblock_param_shapes(u + "encoder.convc2.", 256, 192, K_CONV))
+    sh[u + "encoder.convf1.weight"] = (128, 2, 1, 1); sh[u + "encoder.convf1.bias"] = (128,)
+    sh.update(pcblock_param_shapes(u + "encoder.convf2.", 128, 64, K_CONV))
+    sh.update(pcblock_param_shapes(u + "encoder.conv.", 256, 126, K_CONV))
+    sh.update(pcblock_param_shapes(u + "gru.", 512, 128, K_GRU))
+    sh.update(pcblock_param_shapes(u + "flow_head.", 128, 2, K_CONV))
+    sh[u + "mask.0.weight"] = (256, 128, 3, 3); sh[u + "mask.0.bias"] = (256,)
+    sh[u + "mask.2.weight"] = (576, 256, 1, 1); sh[u + "mask.2.bias"] = (576,)
+    sh[u + "aggregator.to_v.weight"] = (128, 128, 1, 1); sh[u + "aggregator.gamma"] = (1,)
+    sh["att.to_qk.weight"] = (256, 128, 1, 1)
+    sh["att.pos_emb.rel_height.weight"] = (319, 128); sh["att.pos_emb.rel_width.weight"] = (319, 128)
+    sh["att.pos_emb.rel_ind"] = (160, 160)
+    return sh
+
+
 def seeded_state_dict(shapes, seed):
     """Seeded stand-in weights (no checkpoint in the image): He-scaled convs, BatchNorm statistics near identity; the duplicated
     `downsample.1.*` entries repeat `norm3.*`."""
@@ -52,17 +91,25 @@ def seeded_state_dict(shapes, seed):
     for k, s in shapes.items():
         if ".downsample.1." in k:
             continue
-        if k.endswith("num_batches_tracked"):
+        if k.endswith("rel_ind"):                                               # RelPosEmb buffer (gma.py:16-18), unused at inference
+            n = s[0]
+            sd[k] = torch.arange(n).view(1, -1) - torch.arange(n).view(-1, 1) + n - 1
+        elif k.endswith("gamma"):                                               # zero-initialised in the reference; non-zero so the memory read matters
+            sd[k] = torch.tensor([0.5])
+        elif k.endswith("num_batches_tracked"):
             sd[k] = torch.tensor(1, dtype=torch.int64)
         elif k.endswith("running_var"):
             sd[k] = torch.from_numpy((0.5 + g.random(s)).astype(np.float32))
         elif k.endswith("running_mean") or k.endswith("bias"):
-            sd[k] = torch.from_numpy((0.1 * g.standard_normal(s)).astype(np.float32))
+            sd[k] = torch.from_numpy(((0.002 if "flow_head.ffn2.2" in k else 0.1) * g.standard_normal(s)).astype(np.float32))
         elif len(s) == 1:                                                      # norm weight
             sd[k] = torch.from_numpy((0.8 + 0.4 * g.random(s)).astype(np.float32))
         else:
             fan = int(np.prod(s[1:]))
-            sd[k] = torch.from_numpy((g.standard_normal(s) * (2.0 / fan) ** 0.5).astype(np.float32))
+            gain = (1.0 / fan) ** 0.5 if (".ffn" in k or ".pw." in k or ".conv_list." in k) else (2.0 / fan) ** 0.5   # residual branches: keep 15 iterations tame
+            if "flow_head.ffn2.2" in k:
+                gain *= 0.02                                                    # small flow updates: the 15 GRU iterations stay bounded
+            sd[k] = torch.from_numpy((g.standard_normal(s) * gain).astype(np.float32))
     for k in shapes:
         if ".downsample.1." in k:
             sd[k] = sd[k.replace(".downsample.1.", ".norm3.")]

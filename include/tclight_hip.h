@@ -226,6 +226,8 @@ int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, 
  *   rows [B*P, ld] (zero_rest clears the other channels; the reverse computes out = alpha*out + beta*value, alpha 0 = overwrite).
  * tcl_axpy_f16: y = a + s*b.   tcl_upsample_flow_f32: MemFlowNet.upsample_flow -- softmax over the 9 taps of mask_scale*mask (rows
  *   [B*h*w, ldm], channel tap*64 + i*8 + j) applied to the 3x3 neighbourhood of 8*flow [B,2,h,w] -> [B,2,8h,8w]. */
+/* tcl_context_split_f16: MemFlowNet.encode_context (MemFlow.py:112-115): c rows [P,256] -> net = tanh(c[:, :128]), inp = relu(c[:, 128:]). */
+int tcl_context_split_f16(const void* c, void* net, void* inp, long P, hipStream_t st);
 int tcl_dwconv_gelu_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int C, int k, hipStream_t st);
 int tcl_nchw_f32_to_rows_f16(const float* x, void* y, int B, int Cs, int P, int ld, int c0, int zero_rest, hipStream_t st);
 int tcl_rows_f16_to_nchw_f32(const void* x, float* y, int B, int Cs, int P, int ld, int c0, float alpha, float beta, hipStream_t st);

@@ -381,3 +381,20 @@ int tcl_upsample_flow_f32(const float* flow, const void* mask, int ldm, float ma
 }
 
 }  // extern "C"
+
+// MemFlowNet.encode_context (MemFlow.py:112-115): c [P,256] -> net = tanh(c[:, :128]), inp = relu(c[:, 128:])
+__global__ void k_context_split(const _Float16* __restrict__ c, _Float16* __restrict__ net, _Float16* __restrict__ inp, long P) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P * 16; i += (long)gridDim.x * blockDim.x) {
+        const long p = i >> 4; const int ch = (int)(i & 15) * 8;
+        const h8 a = *(const h8*)(c + p * 256 + ch), b = *(const h8*)(c + p * 256 + 128 + ch);
+        h8 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o1[j] = (_Float16)tanhf((float)a[j]); o2[j] = (_Float16)fmaxf((float)b[j], 0.f); }
+        *(h8*)(net + p * 128 + ch) = o1; *(h8*)(inp + p * 128 + ch) = o2;
+    }
+}
+extern "C" int tcl_context_split_f16(const void* c, void* net, void* inp, long P, hipStream_t st) {
+    TCL_CHECK_ARG(c && net && inp && P > 0);
+    hipLaunchKernelGGL(k_context_split, dim3(stream_grid(P * 16, 256, 1)), dim3(256), 0, st, (const _Float16*)c, (_Float16*)net, (_Float16*)inp, P);
+    TCL_LAUNCH_RET();
+}

@@ -242,6 +242,17 @@ class CorrBlock:
         self._hs = (ctypes.c_int * num_levels)(*hs)
         self._ws = (ctypes.c_int * num_levels)(*ws)
 
+    @classmethod
+    def from_nhwc(cls, f1, f2, num_levels=4, radius=4):
+        """f1, f2 [B,H,W,D] f32 NHWC on the device."""
+        return cls(f1.permute(0, 3, 1, 2), f2.permute(0, 3, 1, 2), num_levels, radius)
+
+    def lookup_rows(self, coords, out_rows):
+        """Window lookup written as f16 rows [B*H*W, ld] (first L*(2r+1)^2 channels) for the motion encoder's GEMM."""
+        B, D, H, W = self.shape
+        lib().tcl_corr_lookup_rows_f16(self.f1, self._ptrs, self._hs, self._ws, self.num_levels, coords, out_rows, out_rows.shape[1], B, H, W, D,
+                                       self.radius, stream())
+
     def __call__(self, coords):
         B, D, H, W = self.shape
         n = 2 * self.radius + 1
@@ -249,3 +260,138 @@ class CorrBlock:
         lib().tcl_corr_lookup_f32(self.f1, self._ptrs, self._hs, self._ws, self.num_levels, coords.float().contiguous(), out, B, H, W, D,
                                   self.radius, 1, stream())
         return out
+
+
+# ------------------------------------------------------------------------------------------------ update block + inference core
+class _Lin:
+    """1x1 convolution as a GEMM over channel-padded f16 rows: weight [co64, ci64] (zero rows / columns for the padding), bias [co64]."""
+
+    def __init__(self, w, b, dev):
+        co, ci = w.shape[0], w.shape[1]
+        self.ci, self.co = _up64(ci), _up64(co)
+        self.w = _pad_to(_pad_to(w.reshape(co, ci), 0, self.co), 1, self.ci).to(H16).contiguous().to(dev)
+        self.b = _pad_to(b if b is not None else torch.zeros(co), 0, self.co).to(H16).contiguous().to(dev)
+
+
+class _PCBlock:
+    """PCBlock4_Deep_nopool_res (sk2.py:6-30): x = gelu(x + ffn1(x)); x = gelu(x + dw_k(x)) for k in k_conv; x = gelu(x + pw(x)); ffn2(x)."""
+
+    def __init__(self, f, p, k_conv, dev):
+        lin = lambda q: _Lin(f[q + "weight"], f[q + "bias"], dev)
+        self.f1a, self.f1b, self.pw, self.f2a, self.f2b = lin(p + "ffn1.0."), lin(p + "ffn1.2."), lin(p + "pw."), lin(p + "ffn2.0."), lin(p + "ffn2.2.")
+        self.dw = []
+        for i, k in enumerate(k_conv):
+            w, b = f[p + f"conv_list.{i}.weight"], f[p + f"conv_list.{i}.bias"]
+            c = _up64(w.shape[0])
+            self.dw.append((_pad_to(w.reshape(w.shape[0], k * k).t(), 1, c).to(H16).contiguous().to(dev), _pad_to(b, 0, c).to(H16).contiguous().to(dev), k))
+
+
+class MemFlowEngine:
+    """MemFlowNet (things_memflownet: basicencoder cnet/fnet, GMA-SK2 update block) + InferenceCore + MemoryManager
+    (MemFlow.py:21-183, sk2.py, inference/inference_core_skflow.py:20-54, memory_manager_skflow.py) on the device: f16 NHWC activations
+    with channel counts padded to multiples of 64, f32 coordinates / flow / correlation inputs."""
+
+    def __init__(self, state_dict, device, iters=15, train_avg_length=(400 * 720 // 64) * 3 / 2, max_mt=2, min_mt=1):
+        missing = [k for k in memflow_param_shapes() if k not in state_dict]
+        if missing:
+            raise KeyError(f"MemFlowNet state dict lacks {len(missing)} keys, e.g. {missing[:3]}")
+        self.dev, self.L = torch.device(device), lib()
+        self.iters, self.tal, self.max_mt, self.min_mt = iters, train_avg_length, max_mt, min_mt
+        f = {k: v.float() for k, v in state_dict.items() if v.dtype.is_floating_point}
+        d = self.dev
+        self.fnet = EncoderEngine(state_dict, "fnet.", "instance", d)
+        self.cnet = EncoderEngine(state_dict, "cnet.", "batch", d)
+        u = "update_block."
+        self.convc1, self.convc2 = _PCBlock(f, u + "encoder.convc1.", K_CONV, d), _PCBlock(f, u + "encoder.convc2.", K_CONV, d)
+        self.convf1 = _Lin(f[u + "encoder.convf1.weight"], f[u + "encoder.convf1.bias"], d)
+        self.convf2, self.conv = _PCBlock(f, u + "encoder.convf2.", K_CONV, d), _PCBlock(f, u + "encoder.conv.", K_CONV, d)
+        self.gru, self.flow_head = _PCBlock(f, u + "gru.", K_GRU, d), _PCBlock(f, u + "flow_head.", K_CONV, d)
+        w = f[u + "mask.0.weight"]
+        self.mask0 = (w.permute(0, 2, 3, 1).reshape(256, 9 * 128).to(H16).contiguous().to(d), f[u + "mask.0.bias"].to(H16).to(d))
+        self.mask2 = _Lin(f[u + "mask.2.weight"], f[u + "mask.2.bias"], d)
+        self.to_v = _Lin(f[u + "aggregator.to_v.weight"], None, d)
+        self.gamma = float(f[u + "aggregator.gamma"].item())
+        self.to_qk = _Lin(f["att.to_qk.weight"], None, d)
+        self.scale = 128 ** -0.5                                   # Attention.scale, gma.py:47
+        self.clear_memory()
+
+    def clear_memory(self):
+        self.mem_k = self.mem_v = None                             # rows [T, 128] f16 (working memory, oldest first)
+
+    # ---- building blocks
+    def _gemm(self, x, lin, M, act=0, resid=None, lda=None):
+        y = torch.empty(M, lin.co, dtype=H16, device=self.dev)
+        self.L.tcl_gemm_f16(x, lin.w, lin.b, resid if resid is not None else 0, y, M, lin.co, lin.ci, lda or lin.ci, lin.ci, lin.co, lin.co, act, stream())
+        return y
+
+    def _pc(self, blk, x, B, h, w, out_act=0):
+        M = B * h * w
+        t = self._gemm(x, blk.f1a, M, act=4)
+        x = self._gemm(t, blk.f1b, M, act=5, resid=x)
+        for wd, bd, k in blk.dw:
+            y = torch.empty_like(x)
+            self.L.tcl_dwconv_gelu_f16(x, wd, bd, y, B, h, w, x.shape[1], k, stream())
+            x = y
+        x = self._gemm(x, blk.pw, M, act=5, resid=x)
+        t = self._gemm(x, blk.f2a, M, act=4)
+        return self._gemm(t, blk.f2b, M, act=out_act)
+
+    def _cat(self, a, b, M):
+        y = torch.empty(M, a.shape[1] + b.shape[1], dtype=H16, device=self.dev)
+        self.L.tcl_concat_channels_f16(a, a.shape[1], b, b.shape[1], y, M, stream())
+        return y
+
+    @torch.no_grad()
+    def step(self, images, end=False, flow_init=None):
+        """InferenceCore.step: images [1,2,3,H,W] f32 in [-1,1] (H, W multiples of 8; H/8/8 >= 2) -> (flow_low [1,2,H/8,W/8], flow_up [1,2,H,W])."""
+        L, d = self.L, self.dev
+        images = images.to(d).float()
+        # context: net = tanh(c[:, :128]), inp = relu(c[:, 128:]), (query, key) = to_qk(inp)   (MemFlow.py:112-118)
+        c, (h, w) = self.cnet.forward(images[:, 0])
+        P = h * w
+        net = torch.empty(P, 128, dtype=H16, device=d); inp = torch.empty(P, 128, dtype=H16, device=d)
+        L.tcl_context_split_f16(c, net, inp, P, stream())
+        qk = self._gemm(inp, self.to_qk, P)                        # [P, 256]: query | key
+        key = qk[:, 128:].contiguous()
+        fm, _ = self.fnet.forward(images[0])
+        fm = fm.float().view(2, h, w, 256)
+        corr_fn = CorrBlock.from_nhwc(fm[0:1].contiguous(), fm[1:2].contiguous())
+        ys, xs = torch.meshgrid(torch.arange(h, device=d).float(), torch.arange(w, device=d).float(), indexing="ij")
+        coords0 = torch.stack([xs, ys])[None].contiguous()
+        coords1 = coords0.clone() if flow_init is None else (coords0 + flow_init.to(d).float()).contiguous()
+        corr_rows = torch.zeros(P, 384, dtype=H16, device=d)       # 324 channels + zero padding
+        k_all = key if self.mem_k is None else torch.cat([self.mem_k, key])
+        T = k_all.shape[0]
+        scale = self.scale * np.log(T) / np.log(self.tal)          # memory_manager_skflow.py:59 (math.log(T, train_avg_length))
+        wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P, 128), dtype=torch.uint8, device=d)
+        wkv = torch.empty(L.tcl_attention_kv_bytes(1, 1, T, 128), dtype=torch.uint8, device=d)
+        for it in range(self.iters):
+            corr_fn.lookup_rows(coords1, corr_rows)
+            flow = coords1 - coords0
+            cor = self._pc(self.convc2, self._pc(self.convc1, corr_rows, 1, h, w, out_act=4), 1, h, w)
+            frow = torch.empty(P, 64, dtype=H16, device=d)
+            L.tcl_nchw_f32_to_rows_f16(flow, frow, 1, 2, P, 64, 0, 1, stream())
+            flo = self._pc(self.convf2, self._gemm(frow, self.convf1, P), 1, h, w)
+            mf = self._pc(self.conv, self._cat(cor, flo, P), 1, h, w)          # [P,128]: 126 channels + 2 zero
+            L.tcl_nchw_f32_to_rows_f16(flow, mf, 1, 2, P, 128, 126, 0, stream())  # torch.cat([out, flow], 1)   (sk2.py:128)
+            val = self._gemm(mf, self.to_v, P)
+            v_all = val if self.mem_v is None else torch.cat([self.mem_v, val])
+            ro = torch.empty(P, 128, dtype=H16, device=d)
+            L.tcl_attention_f16(qk, 256, P * 256, k_all, 128, T * 128, v_all, 128, T * 128, ro, 128, P * 128, 1, 1, P, T, 128, float(scale), 1, 1, wq, wkv,
+                                stream())
+            mfg = torch.empty_like(mf)
+            L.tcl_axpy_f16(mf, ro, self.gamma, mfg, mf.numel(), stream())
+            net = self._pc(self.gru, self._cat(self._cat(net, inp, P), self._cat(mf, mfg, P), P), 1, h, w)
+            delta = self._pc(self.flow_head, net, 1, h, w)          # [P,64]: 2 channels + zero padding
+            L.tcl_rows_f16_to_nchw_f32(delta, coords1, 1, 2, P, 64, 0, 1.0, 1.0, stream())
+        m1 = torch.empty(P, 256, dtype=H16, device=d)
+        L.tcl_conv3x3_f16(net, self.mask0[0], self.mask0[1], 0, m1, 1, h, w, 128, 256, 1, 1, 0, 0, 3, stream())
+        mask = self._gemm(m1, self.mask2, P)                       # [P,576]; the 0.25 factor is applied in the upsampling kernel
+        flow_low = coords1 - coords0
+        up = torch.empty(1, 2, 8 * h, 8 * w, dtype=torch.float32, device=d)
+        L.tcl_upsample_flow_f32(flow_low.contiguous(), mask, 576, 0.25, up, 1, h, w, stream())
+        if not end:                                                # mem_every = 1 (inference_core_skflow.py:25, :49-51)
+            self.mem_k, self.mem_v = k_all, v_all
+            if self.mem_k.shape[0] >= self.max_mt * P:             # compress_features: keep the last min_mt frames
+                self.mem_k, self.mem_v = self.mem_k[-self.min_mt * P:].contiguous(), self.mem_v[-self.min_mt * P:].contiguous()
+        return flow_low, up

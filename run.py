@@ -43,16 +43,18 @@ def main(argv=None):
     lo, hi = d.range(len(frame_ids))
     frames_all = parser.load_video(frame_ids)
     flows = parser.load_flow_cache(frame_ids)
-    if flows is None and config.post_opt.apply_opt:
-        raise RuntimeError("stage 1/2 need precomputed optical flow (<video>_{future,past}_flow_memflow/*.pt); flow estimation is not "
-                           "part of this engine yet (SURVEY 8(f)) -- or set post_opt.apply_opt: false")
+    if flows is None and config.post_opt.apply_opt:           # no cache: estimate with MemFlowNet (video_dataparser.py:63-110)
+        from tc_light_amd.memflow import MemFlowEngine
+        from tc_light_amd.model_utils import load_memflow_state
+        flows = parser.estimate_and_cache_flow(frames_all, frame_ids, MemFlowEngine(load_memflow_state((config.get("models") or {}).get("memflow")), dev),
+                                               save_flow=(rank == 0))
     cfg = dict(g); cfg.update(config.post_opt); cfg["seed"] = config.seed
     rmbg = background = None
-    if config.data.get("background_cond"):                     # generate.py:147-167
+    if g.get("background_cond"):                               # generate.py:68-69, 147-167
         from tc_light_amd.model_utils import load_rmbg_state
         from tc_light_amd.rmbg import RMBGEngine
         rmbg = RMBGEngine(load_rmbg_state((config.get("models") or {}).get("rmbg")), dev)
-        background = parser.load_video(path=config.data.background_image_path)
+        background = parser.load_video(path=g.background_image_path)
     gen = Generator(pipe.unet, pipe.vae, cfg, dist=d, scheduler=scheduler, rmbg=rmbg)
     for name, prompt in g.prompt.items():
         conds = encode_prompt_pair(prompt, g.negative_prompt, dev, config.get("models", {}).get("text_encoder"))

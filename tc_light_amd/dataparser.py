@@ -3,7 +3,7 @@
 Frames: .npy / .pt tensors [N,3,H,W] or [N,H,W,3] (uint8 or float), a directory of such per-frame files, or a video container when
 torchvision.io / cv2 is importable (neither is in the target image).  Flow: the reference's on-disk cache format
 `<video>_{past,future}_flow_memflow/%04d.pt` (one [1,2,H,W] tensor per frame, used when the file count matches, :112-132).  Flow
-ESTIMATION (MemFlowNet) is a "next" row and is not part of this engine yet.
+ESTIMATION: `estimate_and_cache_flow` runs the MemFlowNet engine (tc_light_amd/memflow.py) when no cache exists and writes the same files.
 """
 import os
 
@@ -80,16 +80,36 @@ class VideoDataParser:
             fr = fr[list(frame_ids)]
         return process_frames(fr, self.h, self.w).to(self.device)
 
+    def _flow_dir(self, kind):
+        """create_folder (video_dataparser.py:126-131): <video>_<name> beside a file, <dir>/<name> inside a frame directory."""
+        name = f"{kind}_flow_memflow"
+        if os.path.isdir(self.rgb_path):
+            return os.path.join(self.rgb_path, name)
+        return os.path.splitext(self.rgb_path)[0] + "_" + name
+
     def load_flow_cache(self, frame_ids):
-        """-> (future_flows, past_flows) [N,2,H,W] from the reference's .pt cache, or None when absent."""
-        base = os.path.splitext(self.rgb_path)[0]
+        """-> (future_flows, past_flows) [N,2,H,W] from the reference's .pt cache (files named by frame id, used when the file count matches
+        the number of frames, video_dataparser.py:112-116), or None when absent."""
         out = []
         for kind in ("future", "past"):
-            d = f"{base}_{kind}_flow_memflow"
+            d = self._flow_dir(kind)
             if not os.path.isdir(d) or len(os.listdir(d)) != len(frame_ids):
                 return None
-            out.append(torch.cat([torch.load(os.path.join(d, f"{i:04d}.pt")).reshape(1, 2, self.h, self.w) for i in range(len(frame_ids))]))
+            out.append(torch.cat([torch.load(os.path.join(d, f"{fid:04d}.pt")).reshape(1, 2, self.h, self.w) for fid in frame_ids]))
         return out[0].to(self.device), out[1].to(self.device)
+
+    def estimate_and_cache_flow(self, frames, frame_ids, engine, save_flow=True):
+        """load_flow for flow_model 'memflow' (video_dataparser.py:63-110): frames [N,3,h,w] in [0,1] (already processed to the working size)
+        -> (future_flows, past_flows) [N,2,h,w]; saved per frame as [1,2,h,w] tensors under <video>_{future,past}_flow_memflow/%04d.pt."""
+        from .memflow import estimate_flows
+        fut, past = estimate_flows(engine, frames)
+        if save_flow and self.rgb_path:
+            for kind, fl in (("future", fut), ("past", past)):
+                d = self._flow_dir(kind)
+                os.makedirs(d, exist_ok=True)
+                for i, fid in enumerate(frame_ids):
+                    torch.save(fl[i:i + 1].cpu(), os.path.join(d, f"{fid:04d}.pt"))
+        return fut, past
 
 
 def get_frame_ids(frame_range, n_frames, frame_ids=None):

@@ -395,3 +395,57 @@ class MemFlowEngine:
             if self.mem_k.shape[0] >= self.max_mt * P:             # compress_features: keep the last min_mt frames
                 self.mem_k, self.mem_v = self.mem_k[-self.min_mt * P:].contiguous(), self.mem_v[-self.min_mt * P:].contiguous()
         return flow_low, up
+
+
+# ------------------------------------------------------------------------------------------------ video-level driver
+def forward_interpolate(flow):
+    """core/utils/utils.py:32-63 (host, scipy): push every flow vector to where it points and fill by nearest neighbour -- the warm
+    start of the next frame pair (video_dataparser.py:154).  flow [2,h,w] tensor -> [2,h,w] f32 CPU tensor."""
+    from scipy import interpolate
+    f = flow.detach().float().cpu().numpy()
+    dx, dy = f[0], f[1]
+    ht, wd = dx.shape
+    x0, y0 = np.meshgrid(np.arange(wd), np.arange(ht))
+    x1, y1 = (x0 + dx).reshape(-1), (y0 + dy).reshape(-1)
+    dxr, dyr = dx.reshape(-1), dy.reshape(-1)
+    valid = (x1 > 0) & (x1 < wd) & (y1 > 0) & (y1 < ht)
+    x1, y1, dxr, dyr = x1[valid], y1[valid], dxr[valid], dyr[valid]
+    if len(x1) == 0:
+        return torch.zeros(f.shape)
+    fx = interpolate.griddata((x1, y1), dxr, (x0, y0), method="nearest", fill_value=0)
+    fy = interpolate.griddata((x1, y1), dyr, (x0, y0), method="nearest", fill_value=0)
+    return torch.from_numpy(np.stack([fx, fy], axis=0)).float()
+
+
+def _pad8(x):
+    """eval_utils.InputPadder (mode 'sintel'): replicate-pad H, W up to multiples of 8, split evenly."""
+    ht, wd = x.shape[-2:]
+    ph, pw = (((ht // 8) + 1) * 8 - ht) % 8, (((wd // 8) + 1) * 8 - wd) % 8
+    pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
+    return torch.nn.functional.pad(x, pad, mode="replicate"), pad
+
+
+def estimate_flows(engine, frames, warm_start=True):
+    """VideoDataParser.load_flow / calc_flow for the 'memflow' model (video_dataparser.py:63-110, 141-156): frames [N,3,H,W] in [0,1] ->
+    (future_flows, past_flows) [N,2,H,W] f32 on the device.  As in the reference ONE inference core (one working memory) serves the
+    interleaved forward and backward pairs, each direction with its own warm-start chain; the last future flow and the first past flow
+    are zero."""
+    gts = frames.float() * 2.0 - 1.0
+    N = gts.shape[0]
+    fut, past = [], []
+    prev = {True: None, False: None}
+    engine.clear_memory()
+    for idx in range(N):
+        for is_future in (True, False):
+            zero_idx = N - 1 if is_future else 0
+            if idx == zero_idx:
+                flow = torch.zeros_like(gts[idx:idx + 1, :2])
+            else:
+                src, tgt = gts[idx:idx + 1], (gts[idx + 1:idx + 2] if is_future else gts[idx - 1:idx])
+                (src, pad), (tgt, _) = _pad8(src), _pad8(tgt)
+                low, up = engine.step(torch.cat([src, tgt])[None], flow_init=prev[is_future] if warm_start else None)
+                ht, wd = up.shape[-2:]
+                flow = up[..., pad[2]:ht - pad[3], pad[0]:wd - pad[1]]
+                prev[is_future] = forward_interpolate(low[0])[None].to(up.device)
+            (fut if is_future else past).append(flow)
+    return torch.cat(fut), torch.cat(past)

@@ -62,6 +62,16 @@ def load_vae_state(path=None, seed=2):
     return sd15.random_state_dict(shapes, seed)
 
 
+def load_memflow_state(path=None, seed=4):
+    """MemFlowNet_things.pth (eval_utils.py:197-248: torch.load(..., weights_only=True), optional 'module.' prefix) or seeded stand-ins."""
+    from . import memflow
+    if path and os.path.exists(path):
+        raw = torch.load(path, map_location="cpu", weights_only=True)
+        return {(k[7:] if k.startswith("module.") else k): v for k, v in raw.items()}
+    warnings.warn("MemFlowNet weights not found -> seeded random MemFlowNet-shaped weights (the flow is not a trained model's)")
+    return memflow.seeded_state_dict(memflow.memflow_param_shapes(), seed)
+
+
 def load_rmbg_state(path=None, seed=3):
     """briaai/RMBG-1.4 weights (`model.safetensors` / `model.pth` with the reference module's keys, generate.py:149) or seeded stand-ins."""
     from . import rmbg

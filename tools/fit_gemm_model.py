@@ -1,4 +1,4 @@
-"""Fit the GEMM configuration cost model (csrc/gemm.hip: predict_us) to a sweep produced by scratch/tune_gemm.py and report the
+"""Fit the GEMM configuration cost model to a sweep produced by tools/micro/tune_gemm.py and report the
 regret of model-chosen configurations against the per-shape best.  usage: fit_gemm_model.py gpurun_out/tune_gemm.json"""
 import json, math, sys
 import numpy as np

@@ -1,4 +1,4 @@
-import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tc_light_amd import memflow as MF
 sd=MF.seeded_state_dict(MF.memflow_param_shapes(), 31)

@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, time
 from tc_light_amd.rmbg import RMBGEngine, random_state_dict
 e=RMBGEngine(random_state_dict(1),'cuda')

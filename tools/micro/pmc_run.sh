@@ -6,4 +6,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d /tmp/pmcq_$i -o p -- python $GRAFT_REPO_ROOT/$1 > /tmp/pmcq_$i.log 2>&1 || tail -5 /tmp/pmcq_$i.log
 done
-python $GRAFT_REPO_ROOT/scratch/pmc_agg.py "$2" /tmp/pmcq_*/p_counter_collection.csv
+python $GRAFT_REPO_ROOT/tools/micro/pmc_agg.py "$2" /tmp/pmcq_*/p_counter_collection.csv

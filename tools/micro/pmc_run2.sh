@@ -6,4 +6,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d /tmp/pmct_$i -o p -- python $GRAFT_REPO_ROOT/$1 > /tmp/pmct_$i.log 2>&1 || tail -5 /tmp/pmct_$i.log
 done
-python $GRAFT_REPO_ROOT/scratch/pmc_agg.py "$2" /tmp/pmct_*/p_counter_collection.csv
+python $GRAFT_REPO_ROOT/tools/micro/pmc_agg.py "$2" /tmp/pmct_*/p_counter_collection.csv

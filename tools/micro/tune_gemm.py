@@ -1,4 +1,4 @@
-import sys, os, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, collections, numpy as np
 from tc_light_amd import sd15
 from tc_light_amd.unet import UNetEngine, Ops

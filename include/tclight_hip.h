@@ -153,10 +153,14 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
 /* metric / metric.norm(dim=-1) with f16 rounding of the norm and the quotient (merge.py:84, :386). */
 int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t st);
 /* bipartite soft matching with align_batch (merge.py:84-117 randframe, :389-421 2s): cosine scores of src rows a_pos[na]
- * vs dst rows b_pos[nb] of metric [Bt,T,C] (normalised), batch entries concatenated along dst, greedy row max, stable
- * descending order; the r best src rows are merged.  The score matrix is never materialised.
+ * vs dst rows b_pos[nb] of metric [Bt,T,C] (normalised), batch entries concatenated along dst, greedy row max; the r src rows with
+ * the highest f16 score are merged (ties: highest score, lowest concatenated dst index for the match, lowest src index for the cut).
+ * The score matrix is never materialised and nothing is sorted: unmerged src rows keep their index order in the merged sequence (the
+ * reference orders them by score, which only permutes the tokens of a permutation-invariant attention).
  * Outputs: mrg[na-r+nb] = input position feeding each merged slot ([unmerged src | dst], mode "replace");
- *          unm[position] = merged slot each input position is restored from (merge.py:135-155). */
+ *          unm[position] = merged slot each input position is restored from (merge.py:135-155).
+ * ws: tcl_tome_match_workspace_bytes(na) bytes, ZEROED ONCE by the caller before the first call and then only passed to this function
+ * (one stream): every call leaves it all-zero again. */
 size_t tcl_tome_match_workspace_bytes(int na);
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st);

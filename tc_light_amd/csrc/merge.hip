@@ -2,14 +2,13 @@
 // The reference materialises scores [2, n_src, n_dst] in f16, cats the batch along dst, takes row max / argsort.
 // Here: cosine-normalise rows (f16 semantics), one MFMA kernel computes score tiles and reduces them on the fly to a
 // per-src 64-bit key (sortable f16 score << 32 | ~concat_dst_index) with in-lane max + atomicMax -- the score matrix
-// never exists -- then a stable descending radix sort (hipCUB) of the 16-bit scores gives the edge order.  Merging in
+// never exists -- then a single-block top-r selection on the 16-bit scores picks the merged tokens.  Merging in
 // "replace" mode and unmerging are pure row gathers driven by int32 maps built on the device; the global-token bank
 // stays on the device (the reference round-trips it through the CPU for every block and chunk, patch.py:65-82).
 // Tie rule (the reference's is unspecified on GPU): highest score, then lowest concatenated dst index; equal scores
 // keep ascending src order.
 #include "common.h"
 #include "../../include/tclight_hip.h"
-#include <hipcub/hipcub.hpp>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -180,25 +179,89 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 #undef TOME_ISSUE
 }
 
-// after the sort: order[k] = src local index of rank k (descending score).  Build the maps of SURVEY 8(a) A12/A13:
+// Top-r selection and map construction without a sort (replaces key extraction + device radix sort + map building, ~8 launches per match,
+// by 3 small ones).  The r src tokens with the highest f16 score are merged, ties at the threshold go to the lowest src index
+// (= the order a stable descending sort would produce); the reference orders the remaining (unmerged) src slots by score as well, but
+// that order is immaterial -- the merged sequence only feeds a permutation-invariant attention and is mapped back by `unm` -- so they keep
+// their src index order here.  Maps of SURVEY 8(a) A12/A13:
 //  mrg[p]  (p in [0, na-r+nb))  = input position feeding merged slot p          (merge, mode "replace")
 //  unm[pos] (pos in input seq)  = merged slot that input position pos is restored from (unmerge)
-__global__ void k_tome_build_maps(const int* __restrict__ order, const unsigned long long* __restrict__ keys, int na, int nb, int r,
-                                  const int* __restrict__ a_pos, const int* __restrict__ b_pos, int* __restrict__ mrg, int* __restrict__ unm) {
-    const int nun = na - r;
+// pass 1 (one block): threshold score of the r-th largest element (two 8-bit histogram passes over register-cached scores) and, for
+// every chunk of PER consecutive src indices, the number of ties / lower scores before it (exclusive scans) -> aux
+template <int PER>
+__global__ __launch_bounds__(1024) void k_tome_thresh(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ aux) {
+    __shared__ int hist[256];
+    __shared__ int sc_a[1024], sc_b[1024];
+    __shared__ int s_thr, s_take;
+    const int tid = threadIdx.x, i0 = tid * PER;
+    unsigned short sv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sv[j] = i0 + j < na ? (unsigned short)((keys[i0 + j] >> 32) & 0xFFFFu) : (unsigned short)0;
+    int thr = 0x10000, take = 0;                     // r == 0: nothing merged
+    if (r > 0) {
+        int hi_bin = 0, need = r;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (i0 + j >= na) break;
+                const unsigned sc = sv[j];
+                if (pass == 0) atomicAdd(&hist[sc >> 8], 1);
+                else if ((int)(sc >> 8) == hi_bin) atomicAdd(&hist[sc & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, bsel = 0;
+                for (int bq = 255; bq >= 0; --bq) { if (acc + hist[bq] >= need) { bsel = bq; break; } acc += hist[bq]; }
+                s_thr = bsel; s_take = need - acc;             // elements still to take from bin bsel
+            }
+            __syncthreads();
+            if (pass == 0) { hi_bin = s_thr; need = s_take; } else { thr = (hi_bin << 8) | s_thr; take = s_take; }
+            __syncthreads();
+        }
+    }
+    int n_tie = 0, n_low = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (i0 + j >= na) break;
+        n_tie += (int)sv[j] == thr; n_low += (int)sv[j] < thr;
+    }
+    sc_a[tid] = n_tie; sc_b[tid] = n_low;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scans over the 1024 chunk totals
+        const int va = tid >= off ? sc_a[tid - off] : 0, vb = tid >= off ? sc_b[tid - off] : 0;
+        __syncthreads();
+        sc_a[tid] += va; sc_b[tid] += vb;
+        __syncthreads();
+    }
+    aux[2 + 2 * tid] = sc_a[tid] - n_tie; aux[3 + 2 * tid] = sc_b[tid] - n_low;      // exclusive prefixes of chunk tid
+    if (tid == 0) { aux[0] = thr; aux[1] = take; }
+}
+// pass 2 (grid): maps, one thread per src / dst token; also clears keys[] again so the next match needs no memset
+__global__ void k_tome_maps(unsigned long long* __restrict__ keys, const int* __restrict__ aux, int per, int na, int nb, int r,
+                            const int* __restrict__ a_pos, const int* __restrict__ b_pos, int* __restrict__ mrg, int* __restrict__ unm) {
+    const int nun = na - r, thr = aux[0], take = aux[1];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
-        if (i < na) {
-            int s = order[i], pos = a_pos[s];
-            if (i >= r) { mrg[i - r] = pos; unm[pos] = i - r; }
-            else { unsigned cidx = 0xFFFFFFFFu - (unsigned)(keys[s] & 0xFFFFFFFFull); unm[pos] = nun + (int)(cidx % (unsigned)nb); }
+        if (i >= na) { const int j = i - na, pos = b_pos[j]; mrg[nun + j] = pos; unm[pos] = nun + j; continue; }
+        const int c = i / per;
+        int tie_before = aux[2 + 2 * c], low_before = aux[3 + 2 * c];
+        for (int q = c * per; q < i; ++q) { const int sq = (int)((keys[q] >> 32) & 0xFFFFu); tie_before += sq == thr; low_before += sq < thr; }
+        const unsigned long long k = keys[i];
+        const int sc = (int)((k >> 32) & 0xFFFFu), pos = a_pos[i];
+        const bool merged = sc > thr || (sc == thr && tie_before < take);
+        if (merged) {
+            const unsigned cidx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            unm[pos] = nun + (int)(cidx % (unsigned)nb);
         } else {
-            int j = i - na, pos = b_pos[j];
-            mrg[nun + j] = pos; unm[pos] = nun + j;
+            // unmerged slot = number of unmerged src tokens before i = (#lower before) + (#ties before that were not taken)
+            const int slot = low_before + max(tie_before - take, 0);
+            mrg[slot] = pos; unm[pos] = slot;
         }
     }
 }
-__global__ void k_keys_to_sort(const unsigned long long* __restrict__ keys, unsigned* __restrict__ k16, int* __restrict__ iota, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { k16[i] = (unsigned)(keys[i] >> 32); iota[i] = i; }
+__global__ void k_clear_u64(unsigned long long* __restrict__ p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
 }
 // out[i] = outer[off + inner[i]]  (inner NULL = identity)
 __global__ void k_index_compose(const int* __restrict__ outer, const int* __restrict__ inner, int off, int n, int* __restrict__ out) {
@@ -234,24 +297,15 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
     TCL_LAUNCH_RET();
 }
 
-size_t tcl_tome_match_workspace_bytes(int na) {
-    size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, na, 0, 16);
-    return ((size_t)na * 8 + 255) / 256 * 256 + 4 * (((size_t)na * 4 + 255) / 256 * 256) + tmp + 1024;
-}
+size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024) * 4 + 1024; }
 
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
 // Outputs: mrg int32 [na - r + nb], unm int32 [T'] (indexed by input position; every a_pos/b_pos entry is written).
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st) {
-    TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && C % 64 == 0);
-    char* p = (char*)ws;
-    auto take = [&](size_t b) { char* q = p; p += (b + 255) / 256 * 256; return q; };
-    unsigned long long* keys = (unsigned long long*)take((size_t)na * 8);
-    unsigned* k_in = (unsigned*)take((size_t)na * 4); unsigned* k_out = (unsigned*)take((size_t)na * 4);
-    int* v_in = (int*)take((size_t)na * 4); int* order = (int*)take((size_t)na * 4);
-    if (hipMemsetAsync(keys, 0, (size_t)na * 8, st) != hipSuccess) return TCL_ELAUNCH;
+    TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
+    unsigned long long* keys = (unsigned long long*)ws;           // all-zero on entry (caller zeroes once; k_tome_select re-clears)
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
     const size_t lds = (size_t)3 * 256 * 64;
     static bool set = false;
@@ -263,11 +317,13 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     const int nrange = cdiv(ts, spb);
     hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
                        spb, keys);
-    hipLaunchKernelGGL(k_keys_to_sort, dim3(cdiv(na, 256)), dim3(256), 0, st, keys, k_in, v_in, na);
-    size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, k_in, k_out, v_in, order, na, 0, 16, st);
-    if (hipcub::DeviceRadixSort::SortPairsDescending(p, tmp, k_in, k_out, v_in, order, na, 0, 16, st) != hipSuccess) return TCL_ELAUNCH;
-    hipLaunchKernelGGL(k_tome_build_maps, dim3(cdiv(na + nb, 256)), dim3(256), 0, st, order, keys, na, nb, r, a_pos, b_pos, mrg, unm);
+    int* aux = (int*)((char*)ws + ((size_t)na * 8 + 255) / 256 * 256);
+    const int per = na <= 8 * 1024 ? 8 : (na <= 24 * 1024 ? 24 : 64);
+    if (per == 8) hipLaunchKernelGGL(k_tome_thresh<8>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
+    else if (per == 24) hipLaunchKernelGGL(k_tome_thresh<24>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
+    else hipLaunchKernelGGL(k_tome_thresh<64>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
+    hipLaunchKernelGGL(k_tome_maps, dim3(cdiv(na + nb, 256)), dim3(256), 0, st, keys, aux, per, na, nb, r, a_pos, b_pos, mrg, unm);
+    hipLaunchKernelGGL(k_clear_u64, dim3(cdiv(na, 1024)), dim3(256), 0, st, keys, na);
     TCL_LAUNCH_RET();
 }
 int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st) {

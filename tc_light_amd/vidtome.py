@@ -96,7 +96,7 @@ class VidToMe:
             L.tcl_tome_normalize_f16(flat[tbs:], metric[T:], T, C, stream())
         need = L.tcl_tome_match_workspace_bytes(na)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)        # zeroed once; every match leaves it zero again
         mrg = torch.empty(na - r + nb, dtype=I32, device=self.dev)
         unm = torch.empty(T, dtype=I32, device=self.dev)
         L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, self._ws, stream())

@@ -197,8 +197,8 @@ def test_scheduler_vs_oracle(L):
 
 
 def test_vidtome_maps_vs_oracle(L):
-    """Same f16 tokens -> HIP matching vs the oracle's f16-emulating rule: maps must agree except where f32
-    accumulation order flips an f16 rounding (rare)."""
+    """Same f16 tokens -> HIP matching vs the oracle's f16-emulating rule: every token must be restored from the same representative
+    except where f32 accumulation order flips an f16 rounding (rare)."""
     from oracle import vidtome as OV
     from tc_light_amd.vidtome import VidToMe
     g = np.random.default_rng(3)
@@ -215,15 +215,18 @@ def test_vidtome_maps_vs_oracle(L):
         r = OV.compute_merge(x.float(), F, bank, randf, coin, emulate_f16=True)
         assert T == r["merged"].shape[1]
         um = unm.cpu().long() if unm is not None else torch.arange(F * N)
-        agree = (um == r["unm"]).float().mean().item()
+        # slot numbering of the unmerged tokens is free (attention is permutation-invariant; the HIP path keeps them in index order, the
+        # reference in score order): compare what every token is RESTORED from, i.e. unmerge applied to the merged tokens themselves
+        mh = merged.cpu().float()
+        rest_h, rest_o = mh[:, um], r["merged"][:, r["unm"]]
+        agree = (rest_h == rest_o).all(-1).float().mean().item()
         assert agree > 0.995, agree
         if agree == 1.0:
-            # the merged SET must match; the order of unmerged src slots may differ between near-tied scores
-            # (f32 accumulation order -> 1 f16 ulp), which attention is invariant to.
+            # the merged SET must match as well
             hv = torch.from_numpy(g.standard_normal(C).astype(np.float32))
-            a, b = (merged.cpu().float() @ hv).sort(-1).values, (r["merged"] @ hv).sort(-1).values
+            a, b = (mh @ hv).sort(-1).values, (r["merged"] @ hv).sort(-1).values
             assert torch.equal(a, b)
-            assert torch.equal(tome.banks["blk"].cpu().float(), r["bank_new"])
+            assert torch.equal((tome.banks["blk"].cpu().float() @ hv).sort(-1).values, (r["bank_new"] @ hv).sort(-1).values)   # same bank, as a set
         bank = tome.banks["blk"].cpu().float()       # continue the chain from the HIP bank so later rounds stay comparable
 
 

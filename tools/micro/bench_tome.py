@@ -8,7 +8,7 @@ for na,nb,C in [(23760,11880,320),(11880,23760,320),(8100,2700,320),(5940,2970,6
     x=torch.randn(2,T,C,device='cuda').to(H); m=torch.empty_like(x)
     L.tcl_tome_normalize_f16(x,m,2*T,C,st())
     a=torch.arange(0,na,dtype=I,device='cuda'); b=torch.arange(na,T,dtype=I,device='cuda')
-    ws=torch.empty(L.tcl_tome_match_workspace_bytes(na),dtype=torch.uint8,device='cuda')
+    ws=torch.zeros(L.tcl_tome_match_workspace_bytes(na),dtype=torch.uint8,device='cuda')
     r=na//2; mrg=torch.empty(na-r+nb,dtype=I,device='cuda'); unm=torch.empty(T,dtype=I,device='cuda')
     for _ in range(3): L.tcl_tome_match_f16(m,T*C,2,C,a,na,b,nb,r,mrg,unm,ws,st())
     torch.cuda.synchronize()

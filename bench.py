@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--epochs_exposure", type=int, default=35)
     ap.add_argument("--epochs", type=int, default=70)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_extras", action="store_true", help="skip the flow-estimation / matting timings reported beside the metric")
     ap.add_argument("--no_multi_axis", action="store_true")
     return ap.parse_args()
 
@@ -48,6 +49,28 @@ def synth_inputs(n, H, W, lo, hi, dev, seed=12345):
     d = synth.video_clip(n, H, W, seed=seed)
     inv, k = synth.track_ids(n, H, W, seed=3)
     return (d["frames"][lo:hi].to(dev), d["past_flows"].to(dev), d["masks"].to(dev), inv.to(device=dev, dtype=torch.int32), k)
+
+
+def producer_timings(frames, dev):
+    """Stage-2 input producers that the reference runs inside its timed region (generate.py:595) but BASELINE's metric excludes: MemFlowNet
+    flow estimation (both directions, interleaved like video_dataparser.py:63-110, warm start off to keep the host-side scipy step out) and
+    BriaRMBG matting.  Seeded random weights; 8 frames of the workload."""
+    from tc_light_amd import memflow as MF
+    from tc_light_amd import rmbg as RM
+    fr = frames[:8]
+    eng = MF.MemFlowEngine(MF.seeded_state_dict(MF.memflow_param_shapes(), 31), dev)
+    MF.estimate_flows(eng, fr[:2], warm_start=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    MF.estimate_flows(eng, fr, warm_start=False)
+    torch.cuda.synchronize(); t_flow = time.perf_counter() - t0
+    rm = RM.RMBGEngine(RM.random_state_dict(1), dev)
+    rm.estimate_alpha(fr[:2])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rm.estimate_alpha(fr)
+    torch.cuda.synchronize(); t_rm = time.perf_counter() - t0
+    n = fr.shape[0]
+    return {"memflow_ms_per_frame_pair": t_flow / (2 * (n - 1)) * 1e3, "memflow_pairs": 2 * (n - 1), "rmbg_ms_per_frame": t_rm / n * 1e3,
+            "note": "MemFlowNet (15 iterations) and BriaRMBG engines on 8 frames of the workload, seeded random weights; not part of value"}
 
 
 def cpu_baseline(sd_unet, H, W, n_frames, n_steps, multi_axis, flops_path1, cfg):
@@ -227,6 +250,11 @@ def main():
                          "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": measured_traffic(),
                          "unet_algorithmic_tflop_per_pass": unet.flops / 1e12},
         }
+        if world == 1 and not a.no_extras:
+            try:                                               # the SURVEY 8(f) rows, measured beside the metric (never part of `value`)
+                res["producers"] = producer_timings(frames, dev)
+            except Exception as e:
+                res["producers"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, a.n_timesteps, not a.no_multi_axis, unet.flops, cfg)

@@ -225,7 +225,7 @@ int tcl_add_act_f16(const void* a, const void* b, void* y, long n, int act, hipS
 int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, hipStream_t st);
 
 /* ---- MemFlowNet update block (core/Networks/MemFlowNet/sk2.py, MemFlow.py:172-183) -- glue beside the GEMMs, f16 NHWC rows unless noted.
- * tcl_dwconv_gelu_f16: y = gelu(x + depthwise_kxk(x) + bias) (PCBlock4_Deep_nopool_res, sk2.py:26-27); w [k*k, C] f16 (tap-major), k odd.
+ * tcl_dwconv_gelu_f16: y = gelu(x + depthwise_kxk(x) + bias) (PCBlock4_Deep_nopool_res, sk2.py:26-27); w [k*k, C] f16 (tap-major), k in {1, 7, 15} (the sizes sk2.py:201-202 uses).
  * tcl_nchw_f32_to_rows_f16 / tcl_rows_f16_to_nchw_f32: move Cs channels between an f32 NCHW tensor [B,Cs,P] and channels [c0, c0+Cs) of f16
  *   rows [B*P, ld] (zero_rest clears the other channels; the reverse computes out = alpha*out + beta*value, alpha 0 = overwrite).
  * tcl_axpy_f16: y = a + s*b.   tcl_upsample_flow_f32: MemFlowNet.upsample_flow -- softmax over the 9 taps of mask_scale*mask (rows

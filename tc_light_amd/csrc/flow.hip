@@ -36,10 +36,13 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
     if (live) { const float s = 1.f / (float)(1 << l); cx = coords[((long)b * 2 + 0) * P + pix] * s; cy = coords[((long)b * 2 + 1) * P + pix] * s; }
     const float x0f = floorf(cx), y0f = floorf(cy), fx = cx - x0f, fy = cy - y0f;
     const int x0 = (int)x0f - r, y0 = (int)y0f - r;
-    float q[8];
-    const int nv = D >> 6;                                             // D % 64 == 0, D <= 512
-    if (live)
-        for (int j = 0; j < nv; ++j) q[j] = f1[((long)b * P + pix) * D + lane + 64 * j];
+    // lane owns 4 contiguous features of every 256-feature block (float4 loads): D % 256 == 0 -> nv4 blocks, else the scalar layout
+    const int nv4 = (D & 255) == 0 ? D >> 8 : 0, nv = D >> 6;             // D % 64 == 0, D <= 512
+    float4 q4[2]; float q[8];
+    if (live) {
+        if (nv4) for (int j = 0; j < nv4; ++j) q4[j] = *(const float4*)(f1 + ((long)b * P + pix) * D + j * 256 + lane * 4);
+        else for (int j = 0; j < nv; ++j) q[j] = f1[((long)b * P + pix) * D + lane + 64 * j];
+    }
     for (int c0 = 0; c0 < npts; c0 += 32) {
         for (int pt = 0; pt < 32; ++pt) {
             const int p = c0 + pt;
@@ -47,13 +50,18 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
             if (live && p < npts) {
                 const int iy = y0 + p / n1, ix = x0 + p % n1;
                 if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) {
-                    const float* row = g + ((long)iy * Wl + ix) * D + lane;
-                    for (int j = 0; j < nv; ++j) acc += q[j] * row[64 * j];
+                    const float* row = g + ((long)iy * Wl + ix) * D;
+                    if (nv4) {
+                        for (int j = 0; j < nv4; ++j) { const float4 v = *(const float4*)(row + j * 256 + lane * 4); acc += q4[j].x * v.x + q4[j].y * v.y + q4[j].z * v.z + q4[j].w * v.w; }
+                    } else {
+                        for (int j = 0; j < nv; ++j) acc += q[j] * row[lane + 64 * j];
+                    }
                 }
             }
             part[wid][pt][lane] = acc;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                 // part[wid] and dots[wid] are private to this wave: LDS ops of one wave retire in order
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {   // lane sums half of point (lane & 31)'s 64 partials in a fixed order, halves combined by one exchange
             const int pt = lane & 31, h0 = (lane >> 5) * 32;
             float s = 0.f;
@@ -61,7 +69,8 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
             s += __shfl_xor(s, 32, 64);
             if (lane < 32 && c0 + pt < npts) dots[wid][c0 + pt] = s;
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
     if (!live) return;
     OT* o = out + (long)b * out_bs + (long)pix * out_ps + (long)l * n * n * out_cs;
@@ -263,34 +272,58 @@ int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, 
 // MemFlowNet update block (core/Networks/MemFlowNet/sk2.py): depthwise large-kernel convolution of PCBlock4_Deep_nopool_res fused with
 // its residual and GELU, and the small f32 <-> padded-f16 glue around the GEMMs.
 
-// y = gelu(x + depthwise_kxk(x) + bias)  (sk2.py:26-27: `x = F.gelu(x + conv(x))`); x, y [B,H,W,C] f16 NHWC, w [k*k][C] f16, k odd
+// y = gelu(x + depthwise_kxk(x) + bias)  (sk2.py:26-27: `x = F.gelu(x + conv(x))`); x, y [B,H,W,C] f16 NHWC, w [k*k][C] f16, k odd.
+// Block = 16x16 output pixels x 8 channels: the (16+k-1)^2 input halo of those 8 channels is staged in LDS once (16 B per pixel), every
+// thread then reads its k*k taps from LDS; the 8-channel weight vectors are block-uniform (scalar loads).
+template <int K>
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
-                                                     _Float16* __restrict__ y, int H, int W, int C, int k) {
-    const int b = blockIdx.z, ch = blockIdx.y * 8, p = blockIdx.x * 256 + threadIdx.x, P = H * W;
-    if (p >= P) return;
-    const int oy = p / W, ox = p - oy * W, r = k >> 1;
+                                                     _Float16* __restrict__ y, int H, int W, int C) {
+    constexpr int R = K / 2, TS = 16 + K - 1;
+    __shared__ h8 tile[TS * TS];
+    const int b = blockIdx.z, ch = blockIdx.y * 8, tilesx = (W + 15) / 16;
+    const int ty0 = (blockIdx.x / tilesx) * 16, tx0 = (blockIdx.x % tilesx) * 16;
+    const _Float16* xb = x + (long)b * H * W * C + ch;
+    for (int i = threadIdx.x; i < TS * TS; i += 256) {
+        const int iy = ty0 - R + i / TS, ix = tx0 - R + i % TS;
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const h8*)(xb + ((long)iy * W + ix) * C);
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, oy = ty0 + ly, ox = tx0 + lx;
+    if (oy >= H || ox >= W) return;
     float acc[8];
     const h8 bv = *(const h8*)(bias + ch);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (float)bv[j];
-    const _Float16* xb = x + (long)b * P * C + ch;
-    for (int ky = 0; ky < k; ++ky) {
-        const int iy = oy - r + ky;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < k; ++kx) {
-            const int ix = ox - r + kx;
-            if (ix < 0 || ix >= W) continue;
-            const h8 v = *(const h8*)(xb + ((long)iy * W + ix) * C);
-            const h8 wv = *(const h8*)(w + (long)(ky * k + kx) * C + ch);        // block-uniform
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const h8 v = tile[(ly + ky) * TS + lx + kx];
+            const h8 wv = *(const h8*)(w + (long)(ky * K + kx) * C + ch);        // block-uniform
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * (float)wv[j];
         }
-    }
-    const h8 xc = *(const h8*)(xb + (long)p * C);
+    const h8 xc = tile[(ly + R) * TS + lx + R];
     h8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float t = (float)xc[j] + acc[j]; o[j] = (_Float16)(0.5f * t * (1.f + erff(t * 0.70710678f))); }
-    *(h8*)(y + ((long)b * P + p) * C + ch) = o;
+    *(h8*)(y + (((long)b * H + oy) * W + ox) * C + ch) = o;
+}
+// k == 1: per-channel scale and bias
+__global__ void k_dw1_gelu(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias, _Float16* __restrict__ y,
+                           long rows, int C) {
+    const int nchunk = C / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * nchunk; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nchunk) * 8;
+        const h8 v = *(const h8*)(x + (i / nchunk) * C + ch), wv = *(const h8*)(w + ch), bv = *(const h8*)(bias + ch);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = (float)v[j] + (float)v[j] * (float)wv[j] + (float)bv[j]; o[j] = (_Float16)(0.5f * t * (1.f + erff(t * 0.70710678f))); }
+        *(h8*)(y + (i / nchunk) * C + ch) = o;
+    }
 }
 
 // f32 NCHW [B,Cs,H,W] -> f16 NHWC rows [B*H*W, ld] channels [c0, c0+Cs) (other channels untouched unless zero_rest)
@@ -354,9 +387,12 @@ __global__ void k_upsample_flow(const float* __restrict__ flow, const _Float16* 
 extern "C" {
 
 int tcl_dwconv_gelu_f16(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int C, int k, hipStream_t st) {
-    TCL_CHECK_ARG(x && w && bias && y && B > 0 && H > 0 && W > 0 && C % 8 == 0 && k >= 1 && (k & 1));
-    hipLaunchKernelGGL(k_dwconv_gelu, dim3(cdiv((long)H * W, 256), C / 8, B), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
-                       (_Float16*)y, H, W, C, k);
+    TCL_CHECK_ARG(x && w && bias && y && B > 0 && H > 0 && W > 0 && C % 8 == 0 && (k == 1 || k == 7 || k == 15));
+    const _Float16 *xp = (const _Float16*)x, *wp = (const _Float16*)w, *bp = (const _Float16*)bias;
+    const dim3 grid(cdiv(H, 16) * cdiv(W, 16), C / 8, B);
+    if (k == 1) hipLaunchKernelGGL(k_dw1_gelu, dim3(stream_grid((long)B * H * W * (C / 8), 256, 2)), dim3(256), 0, st, xp, wp, bp, (_Float16*)y, (long)B * H * W, C);
+    else if (k == 7) hipLaunchKernelGGL(k_dwconv_gelu<7>, grid, dim3(256), 0, st, xp, wp, bp, (_Float16*)y, H, W, C);
+    else hipLaunchKernelGGL(k_dwconv_gelu<15>, grid, dim3(256), 0, st, xp, wp, bp, (_Float16*)y, H, W, C);
     TCL_LAUNCH_RET();
 }
 int tcl_nchw_f32_to_rows_f16(const float* x, void* y, int B, int Cs, int P, int ld, int c0, int zero_rest, hipStream_t st) {

@@ -2,7 +2,7 @@
 //   C[M,N] (f16) = act( A[M,K] (f16) . W[N,K]^T (f16) + bias[N] ) + residual[M,N]      (f32 accumulate)
 // This single kernel family carries every dense contraction of path 1: Linear / conv1x1 (dense A),
 // conv3x3 stride 1|2 with optional nearest-upsampled input (A rows gathered on the fly from NHWC
-// activations, K = 9*Cin tap-major), see SURVEY 8(a) A9.  Replaces the cuBLAS/cuDNN calls that
+// activations, K = 9*Cin, weights tap-major, walked channel-slice-major: conv_kmap in gemm_conv.h), see SURVEY 8(a) A9.  Replaces the cuBLAS/cuDNN calls that
 // diffusers' UNet2DConditionModel / AutoencoderKL make (reference call sites generate.py:342-347,
 // utils/VidToMe/generate_utils.py:144,161).
 //
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
 #define GEMM_GLOAD(KT, S)                                                                                                     \
     {                                                                                                                         \
         const int k0_ = (KT) * BK;                                                                                            \
-        int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
-        if (cp.conv) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }          \
+        int tdy_ = 0, tdx_ = 0, c0_ = k0_, kw_ = k0_;                                                                         \
+        if (cp.conv) { int tap_ = conv_kmap(k0_, cp.Cin, c0_); tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; kw_ = tap_ * cp.Cin + c0_; } \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                                   \
             u32x4 v_ = {0u, 0u, 0u, 0u};                                                                                      \
             if (a_ok[i]) {                                                                                                    \
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
             }                                                                                                                 \
             ra[S][i] = v_;                                                                                                    \
         }                                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) { u32x4 z_ = {0u, 0u, 0u, 0u}; rb[S][i] = w_ok[i] ? *(const u32x4*)(wp[i] + k0_) : z_; } \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) { u32x4 z_ = {0u, 0u, 0u, 0u}; rb[S][i] = w_ok[i] ? *(const u32x4*)(wp[i] + kw_) : z_; } \
     }
 #define GEMM_SSTORE(S)                                                                                                        \
     {                                                                                                                         \
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
 #define DMA_ISSUE(KT, BUF)                                                                                                    \
     {                                                                                                                         \
         const int k0_ = (kbeg + (KT)) * KB;                                                                                   \
-        int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
-        if (cp.conv) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }          \
+        int tdy_ = 0, tdx_ = 0, c0_ = k0_, kw_ = k0_;                                                                         \
+        if (cp.conv) { int tap_ = conv_kmap(k0_, cp.Cin, c0_); tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; kw_ = tap_ * cp.Cin + c0_; } \
         char* sb_ = smem + (BUF) * STAGE;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                                                   \
             const _Float16* src_ = zero;                                                                                      \
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
                                              (__attribute__((address_space(3))) void*)(sb_ + (wid * A_IT + i) * 1024), 16, 0, 0); \
         }                                                                                                                     \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                                                   \
-            const _Float16* src_ = wp[i] ? wp[i] + k0_ : zero;                                                                \
+            const _Float16* src_ = wp[i] ? wp[i] + kw_ : zero;                                                                \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
                                              (__attribute__((address_space(3))) void*)(sb_ + BM * ROWB + (wid * B_IT + i) * 1024), 16, 0, 0); \
         }                                                                                                                     \

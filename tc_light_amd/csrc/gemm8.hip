@@ -23,6 +23,7 @@
 #include "common.h"
 #include "../../include/tclight_hip.h"
 #include "gemm_conv.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
 #define G8_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
 #define G8_ISSUE2(KT)                                                                                                         \
     {                                                                                                                         \
-        const int k0_ = (KT) * KB;                                                                                            \
+        int k0_ = (KT) * KB;                                                                                                  \
         const int nst_ = (KT) + 1 < nk ? 2 : 1;                                                                               \
         int tdy_ = 0, tdx_ = 0, c0_ = k0_;                                                                                    \
-        if (CONV) { int tap_ = k0_ / cp.Cin; c0_ = k0_ - tap_ * cp.Cin; tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; }             \
+        if (CONV) { const int tap_ = conv_kmap(k0_, cp.Cin, c0_); tdy_ = tap_ / 3; tdx_ = tap_ - tdy_ * 3; k0_ = tap_ * cp.Cin + c0_; }   \
         const _Float16* sa_[NPA];                                                                                             \
         _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                                    \
             if (!CONV) sa_[i] = ap[i] ? ap[i] + k0_ : nullptr;                                                                \

@@ -10,6 +10,16 @@ struct ConvP {
     float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
 };
 
+// K order of the implicit 3x3 convolution, shared by every GEMM kernel so that they all accumulate in the same order (results are
+// bit-identical across tile configurations).  The weights are stored tap-major ([Cout][9][Cin]); the kernels WALK K channel-slice-major
+// when Cin % 64 == 0: the 64-wide step q covers channels (q/9)*64.. of tap q%9, so nine consecutive steps re-touch the same input rows
+// (one 128-B line per pixel, L1/L2-resident) instead of striding through all Cin channels of one tap.  k0 is the linear step start
+// (a multiple of 32); returns the tap and sets c0 (channel offset); the weight column is tap*Cin + c0.
+__device__ __forceinline__ int conv_kmap(int k0, int Cin, int& c0) {
+    if ((Cin & 63) == 0) { const int q = k0 >> 6, c64 = q / 9; c0 = c64 * 64 + (k0 & 63); return q - c64 * 9; }
+    const int tap = k0 / Cin; c0 = k0 - tap * Cin; return tap;
+}
+
 // epilogue activations: 1 SiLU, 3 ReLU, 4 GELU (erf); 0, 2 (GEGLU, applied on column pairs by the caller) and 5 (GELU applied AFTER the
 // residual add, see post_act) leave v unchanged
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -245,7 +245,7 @@ def main():
                        "frames_total": n_total, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
                        "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
-            "roofline": {"bound": "mfma", "kernel": "k_flash<40,48,64,QB,3> (head_dim 40 attention, self + text; QB = 2 query blocks per wave on long sequences, else 1)", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "k_flash<40,48,64,QB,NSTG,TPB> (head_dim 40 attention, self + text; 2 query blocks per wave, 4-slot ring, 2 tiles per barrier on long sequences, else 1 block, 3 slots)", "achieved": ach,
                          "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
                          "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": measured_traffic(),
                          "unet_algorithmic_tflop_per_pass": unet.flops / 1e12},

@@ -84,8 +84,14 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
 // as the B operand of O^T += V^T.P^T; row sums come out of the same MFMA through the ones-row of the V^T panel.
 __device__ __attribute__((aligned(16))) unsigned g_flash_zero[64];
 
-template <int D, int DP, int DPV, int QB, int NSTG>
-__global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+// max over the two 32-lane halves without the LDS round trip of a shuffle: v_permlane32_swap exchanges a's upper half with b's lower half
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB>
+__global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
@@ -141,14 +147,7 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(cons
             for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
     }
 
-    // ring of NSTG slots, prefetch distance NSTG - 1: tile it+NSTG-1 goes into the slot tile it-1 just left
-    FLASH_ISSUE(0);
-    if (NSTG == 3 && nt > 1) FLASH_ISSUE(1);
-    for (int it = 0; it < nt; ++it) {
-        if (NSTG == 3 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // every wave's pieces of tile it landed; everyone is done with tile it-1
-        if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);
+    auto tile = [&](const int it) __attribute__((always_inline)) {
         const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
         const _Float16* vt = kt + KV_TILE * KS;
         const bool mask = __builtin_amdgcn_readfirstlane((int)(it >= nfull));
@@ -158,28 +157,35 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(cons
 #pragma unroll
             for (int ks = 0; ks < NQK; ++ks) kf[blk][ks] = *(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16);
         half8 pf[QB][2][2];
+        // all QK^T MFMAs of the tile first (QB * 2 * NQK back to back): the row-maximum VALU work of query block 0 then runs under the
+        // MFMAs of query block 1 still in the pipe, instead of each block's maximum waiting for its own MFMAs with the pipe idle
+        float16v sacc[QB][2];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float16v s[2];
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+                for (int r = 0; r < 16; ++r) sacc[qb][blk][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NQK; ++ks) s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[blk][ks], qf[qb][ks], s[blk], 0, 0, 0);
+                for (int ks = 0; ks < NQK; ++ks) sacc[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[blk][ks], qf[qb][ks], sacc[qb][blk], 0, 0, 0);
             }
-            if (mask) {                                // scalar branch: only the last tile has padded keys
+        if (mask) {                                    // scalar branch: only the last tile has padded keys
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) s[blk][r] = -1e30f; }
-            }
+                    for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) sacc[qb][blk][r] = -1e30f; }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float16v (&s)[2] = sacc[qb];
             float mx = s[0][0];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             float ps = 0.f;
             if (FOLD) {
                 // The running shift m (kept f16-representable) rides in the spare Q column D against a ones column of the K panel, so the
@@ -232,6 +238,32 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(cons
                     for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][blk][ss], o[qb][t], 0, 0, 0);
                 }
             }
+    };
+    if constexpr (TPB == 2) {
+        // 4-slot ring, two tiles per barrier: tiles it, it+1 are consumed while it+2, it+3 stream into the slots of it-2, it-1 --
+        // half the rendezvous of the one-tile loop (the waves of a block sit on four SIMDs with different partners and drift apart)
+        static_assert(NSTG == 4, "two tiles per barrier need a 4-slot ring");
+        FLASH_ISSUE(0);
+        if (nt > 1) FLASH_ISSUE(1);
+        for (int it = 0; it < nt; it += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // tiles it, it+1 landed for every wave; everyone is done with it-2, it-1
+            if (it + 2 < nt) FLASH_ISSUE(it + 2);
+            if (it + 3 < nt) FLASH_ISSUE(it + 3);
+            tile(it);
+            if (it + 1 < nt) tile(it + 1);
+        }
+    } else {
+        // ring of NSTG slots, prefetch distance NSTG - 1: tile it+NSTG-1 goes into the slot tile it-1 just left
+        FLASH_ISSUE(0);
+        if (NSTG == 3 && nt > 1) FLASH_ISSUE(1);
+        for (int it = 0; it < nt; ++it) {
+            if (NSTG == 3 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave's pieces of tile it landed; everyone is done with tile it-1
+            if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);
+            tile(it);
+        }
     }
 #undef FLASH_ISSUE
     // ---- epilogue
@@ -268,19 +300,19 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 ? 3 : 2) void k_flash(cons
 struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
 static FlashProf g_prof;
 
-template <int D, int DP, int DPV, int QB, int NSTG>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
     constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
-    if (prof) { hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
+    if (prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -296,10 +328,10 @@ int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches)
     double ms = 0.0;
     for (size_t i = 0; i + 1 < g_prof.ev.size(); i += 2) {
         float t = 0.f;
-        hipEventSynchronize(g_prof.ev[i + 1]);
-        hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        (void)hipEventSynchronize(g_prof.ev[i + 1]);
+        (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
         ms += t;
-        hipEventDestroy(g_prof.ev[i]); hipEventDestroy(g_prof.ev[i + 1]);
+        (void)hipEventDestroy(g_prof.ev[i]); (void)hipEventDestroy(g_prof.ev[i + 1]);
     }
     *total_ms = ms; *total_flops = g_prof.flops; *launches = g_prof.launches;
     g_prof.on = false; g_prof.ev.clear();
@@ -333,10 +365,12 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
                            d == 40 ? d : -1);
         hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV);
     }
-    // d = 40: two query blocks per wave (shared K/V fragments) when the grid still fills the chip several times over, else one;
+    // d = 40: two query blocks per wave (shared K/V fragments), 4-slot ring and two tiles per barrier (2 blocks per CU either way: +4.5%)
+    // when the grid still fills the chip several times over, else one block per wave, 3-slot ring, 3 blocks per CU (there the 4-slot
+    // ring would cost a block of occupancy: -6%; -20% for d = 80);
     // d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
     const bool qb2 = (long)B * H * (Tqp / 256) >= 1024;
-    if (d == 40) return qb2 ? launch_flash<40, 48, 64, 2, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+    if (d == 40) return qb2 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
                             : launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read

@@ -13,3 +13,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pm_FETCH_SIZE/pm_counter_collection.csv /tmp/pm_WRITE_SIZE/pm_counter_collection.csv k_flashILi40 > $OUT/flash40_traffic.json
 cat $OUT/flash40_traffic.json; tail -1 $OUT/bench_under_rocprof.json | cut -c1-300
+# SQ counters of the head_dim-40 flash kernel alone (tools/micro/pmc_attn.py: B=2, H=8, T=35640, the merged xy-plane sequence of config 2):
+# MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader cycles), shader cycles = GRBM_GUI_ACTIVE / 8 XCDs
+bash $GRAFT_REPO_ROOT/tools/micro/pmc_run.sh tools/micro/pmc_attn.py k_flashILi40 > $OUT/flash40_sq_counters.txt 2>&1
+python - "$OUT/flash40_sq_counters.txt" <<'PY' >> $OUT/flash40_sq_counters.txt
+import sys
+v = {}
+for l in open(sys.argv[1]):
+    p = l.split()
+    if len(p) >= 2 and p[0].isupper():
+        try: v[p[0]] = float(p[1])
+        except ValueError: pass
+cyc = v["GRBM_GUI_ACTIVE"] / 8
+print(f"shader_cycles_per_launch {cyc:.4g}")
+print(f"mfma_pipe_utilisation {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.4f}   (1024 SIMDs)")
+print(f"valu_active_fraction {4 * v['SQ_ACTIVE_INST_VALU'] / (1024 * cyc):.4f}   (quad-cycle counter x4)")
+print(f"wave_time_split active/issue-stall/parked {v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.3f} / {v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES']:.3f} / {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.3f}")
+PY
+cat $OUT/flash40_sq_counters.txt | tail -5

@@ -186,40 +186,42 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 // their src index order here.  Maps of SURVEY 8(a) A12/A13:
 //  mrg[p]  (p in [0, na-r+nb))  = input position feeding merged slot p          (merge, mode "replace")
 //  unm[pos] (pos in input seq)  = merged slot that input position pos is restored from (unmerge)
-// pass 1 (one block): threshold score of the r-th largest element (two 8-bit histogram passes over register-cached scores) and, for
+// pass 1 (one block): threshold score of the r-th largest element (bitwise radix select over register-cached scores) and, for
 // every chunk of PER consecutive src indices, the number of ties / lower scores before it (exclusive scans) -> aux
 template <int PER>
 __global__ __launch_bounds__(1024) void k_tome_thresh(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ aux) {
-    __shared__ int hist[256];
     __shared__ int sc_a[1024], sc_b[1024];
-    __shared__ int s_thr, s_take;
     const int tid = threadIdx.x, i0 = tid * PER;
     unsigned short sv[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) sv[j] = i0 + j < na ? (unsigned short)((keys[i0 + j] >> 32) & 0xFFFFu) : (unsigned short)0;
     int thr = 0x10000, take = 0;                     // r == 0: nothing merged
     if (r > 0) {
-        int hi_bin = 0, need = r;
-        for (int pass = 0; pass < 2; ++pass) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
+        // Radix select of the r-th largest 16-bit score, one bit per pass from the MSB, on the scores held in registers: count the
+        // candidates that match the decided prefix and have this bit set; if they cover what is still needed the threshold has the
+        // bit, else all of them lie above the threshold and are taken.  No atomics (cosine scores crowd into a few histogram bins:
+        // the LDS-atomic histogram this replaces serialised on them -- 218 us at 64k keys, now ~16), one barrier per pass: wave sums
+        // by ballot + popcount over the bits of the per-thread count, cross-wave through a double-buffered 16-entry LDS array.
+        const int lane = tid & 63, wv = tid >> 6;
+        int prefix = 0, need = r;
+        for (int bit = 15; bit >= 0; --bit) {
+            const unsigned cand = (unsigned)prefix | (1u << bit), mask = 0xFFFFu & ~((1u << bit) - 1u);
+            int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                if (i0 + j >= na) break;
-                const unsigned sc = sv[j];
-                if (pass == 0) atomicAdd(&hist[sc >> 8], 1);
-                else if ((int)(sc >> 8) == hi_bin) atomicAdd(&hist[sc & 255], 1);
-            }
+            for (int j = 0; j < PER; ++j) cnt += ((unsigned)sv[j] & mask) == cand;      // out-of-range slots hold 0 and never match (cand != 0)
+            int wsum = 0;
+#pragma unroll
+            for (int bq = 0; (1 << bq) <= PER; ++bq) wsum += __popcll(__ballot((cnt >> bq) & 1)) << bq;
+            int* buf = sc_a + (bit & 1) * 16;
+            if (lane == 0) buf[wv] = wsum;
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, bsel = 0;
-                for (int bq = 255; bq >= 0; --bq) { if (acc + hist[bq] >= need) { bsel = bq; break; } acc += hist[bq]; }
-                s_thr = bsel; s_take = need - acc;             // elements still to take from bin bsel
-            }
-            __syncthreads();
-            if (pass == 0) { hi_bin = s_thr; need = s_take; } else { thr = (hi_bin << 8) | s_thr; take = s_take; }
-            __syncthreads();
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) tot += buf[w];
+            if (tot >= need) prefix = (int)cand; else need -= tot;
         }
+        thr = prefix; take = need;
+        __syncthreads();                                // sc_a is reused by the scans below
     }
     int n_tie = 0, n_low = 0;
 #pragma unroll
@@ -309,7 +311,7 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
     const size_t lds = (size_t)3 * 256 * 64;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     // each block keeps one dst tile and streams a run of src tiles; runs as long as possible while ~4 blocks per slot (256 CUs x 3) remain
     int spb = (int)((long)ts * td * Bt / 3072);
     if (spb < 1) spb = 1;

@@ -240,30 +240,40 @@ __global__ __launch_bounds__(1024) void k_tome_thresh(const unsigned long long* 
     aux[2 + 2 * tid] = sc_a[tid] - n_tie; aux[3 + 2 * tid] = sc_b[tid] - n_low;      // exclusive prefixes of chunk tid
     if (tid == 0) { aux[0] = thr; aux[1] = take; }
 }
-// pass 2 (grid): maps, one thread per src / dst token; also clears keys[] again so the next match needs no memset
-__global__ void k_tome_maps(unsigned long long* __restrict__ keys, const int* __restrict__ aux, int per, int na, int nb, int r,
-                            const int* __restrict__ a_pos, const int* __restrict__ b_pos, int* __restrict__ mrg, int* __restrict__ unm) {
-    const int nun = na - r, thr = aux[0], take = aux[1];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
-        if (i >= na) { const int j = i - na, pos = b_pos[j]; mrg[nun + j] = pos; unm[pos] = nun + j; continue; }
-        const int c = i / per;
-        int tie_before = aux[2 + 2 * c], low_before = aux[3 + 2 * c];
-        for (int q = c * per; q < i; ++q) { const int sq = (int)((keys[q] >> 32) & 0xFFFFu); tie_before += sq == thr; low_before += sq < thr; }
-        const unsigned long long k = keys[i];
-        const int sc = (int)((k >> 32) & 0xFFFFu), pos = a_pos[i];
-        const bool merged = sc > thr || (sc == thr && tie_before < take);
-        if (merged) {
-            const unsigned cidx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-            unm[pos] = nun + (int)(cidx % (unsigned)nb);
-        } else {
-            // unmerged slot = number of unmerged src tokens before i = (#lower before) + (#ties before that were not taken)
-            const int slot = low_before + max(tie_before - take, 0);
-            mrg[slot] = pos; unm[pos] = slot;
-        }
+// pass 2 (grid): maps, one thread per src / dst token.  Blocks of 192 threads (a multiple of every PER) own whole PER-chunks of src
+// tokens: the scores of the block are staged in LDS for the in-chunk tie / lower counts, and once the block has read them each
+// thread clears its own key, so the next match needs no memset and no extra launch.  Blocks >= nsb map the dst tokens.
+#define TOME_MAPS_BS 192
+__global__ __launch_bounds__(TOME_MAPS_BS) void k_tome_maps(unsigned long long* __restrict__ keys, const int* __restrict__ aux, int per, int na, int nb,
+                                                            int r, int nsb, const int* __restrict__ a_pos, const int* __restrict__ b_pos,
+                                                            int* __restrict__ mrg, int* __restrict__ unm) {
+    __shared__ unsigned short ssc[TOME_MAPS_BS];
+    const int nun = na - r, tid = threadIdx.x;
+    if ((int)blockIdx.x >= nsb) {
+        const int j = ((int)blockIdx.x - nsb) * TOME_MAPS_BS + tid;
+        if (j < nb) { const int pos = b_pos[j]; mrg[nun + j] = pos; unm[pos] = nun + j; }
+        return;
     }
-}
-__global__ void k_clear_u64(unsigned long long* __restrict__ p, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
+    const int i = blockIdx.x * TOME_MAPS_BS + tid;
+    const unsigned long long k = i < na ? keys[i] : 0ull;
+    const int sc = (int)((k >> 32) & 0xFFFFu);
+    ssc[tid] = (unsigned short)sc;
+    __syncthreads();
+    if (i >= na) return;
+    keys[i] = 0ull;
+    const int thr = aux[0], take = aux[1], c = i / per, t0 = tid - (i - c * per);
+    int tie_before = aux[2 + 2 * c], low_before = aux[3 + 2 * c];
+    for (int q = t0; q < tid; ++q) { const int sq = ssc[q]; tie_before += sq == thr; low_before += sq < thr; }
+    const int pos = a_pos[i];
+    const bool merged = sc > thr || (sc == thr && tie_before < take);
+    if (merged) {
+        const unsigned cidx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+        unm[pos] = nun + (int)(cidx % (unsigned)nb);
+    } else {
+        // unmerged slot = number of unmerged src tokens before i = (#lower before) + (#ties before that were not taken)
+        const int slot = low_before + max(tie_before - take, 0);
+        mrg[slot] = pos; unm[pos] = slot;
+    }
 }
 // out[i] = outer[off + inner[i]]  (inner NULL = identity)
 __global__ void k_index_compose(const int* __restrict__ outer, const int* __restrict__ inner, int off, int n, int* __restrict__ out) {
@@ -324,8 +334,8 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     if (per == 8) hipLaunchKernelGGL(k_tome_thresh<8>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
     else if (per == 24) hipLaunchKernelGGL(k_tome_thresh<24>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
     else hipLaunchKernelGGL(k_tome_thresh<64>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
-    hipLaunchKernelGGL(k_tome_maps, dim3(cdiv(na + nb, 256)), dim3(256), 0, st, keys, aux, per, na, nb, r, a_pos, b_pos, mrg, unm);
-    hipLaunchKernelGGL(k_clear_u64, dim3(cdiv(na, 1024)), dim3(256), 0, st, keys, na);
+    const int nsb = cdiv(na, TOME_MAPS_BS);
+    hipLaunchKernelGGL(k_tome_maps, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, aux, per, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();
 }
 int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st) {

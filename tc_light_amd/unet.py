@@ -7,6 +7,7 @@ Activations are NHWC f16 [B, H*W, C]; every op below is one C-ABI call (tc_light
 sequences launches and owns buffers; there is no torch arithmetic on the data path.
 """
 import math
+import os
 
 import torch
 
@@ -213,6 +214,11 @@ class UNetEngine:
             hit = blk["text_kv"][key] = dict(kv=kv, ws=ws, packed=False, L=Lt, text=text)
         return hit
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
     def _transformer(self, p, x, B, Fs, Hh, Ww, text):
         """x [B*N, C] with B = 2*sum(Fs) samples: the unconditional samples of all chunks (chunk order), then the conditional ones.
         Everything is batched over the chunks except attn1 of the merging levels, which runs chunk by chunk in the reference order
@@ -234,15 +240,33 @@ class UNetEngine:
             self._fl(2.0 * M * C * C * 4 + 4.0 * B * N * N * C)
         else:
             off, xbs = 0, Ftot * N * C                          # a chunk's conditional rows sit xbs elements after its unconditional ones
+            # The matching chain (bank order, dozens of small launches per chunk) runs on a side stream, ahead of the attention of the
+            # chunks already matched: only merge(c) -> merge(c+1) and merge(c) -> attention(c) are real dependencies, so the small
+            # kernels of chunk c+1 fill the tails of chunk c's QKV GEMM / flash launches instead of serialising with them.
+            main = torch.cuda.current_stream()
+            # (Always on the side stream, single-chunk passes included: the banks then live in that stream's allocator pool for good.)
+            two = os.environ.get("TCL_TOME_STREAM", "1") != "0"
+            side = self._side_stream() if two else main
+            if two:
+                side.wait_stream(main)                          # n1 is ready
             for ci, F in enumerate(Fs):
                 self.tome.select_chunk(ci)
-                merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs)     # merged [2, T, C]
+                with torch.cuda.stream(side):
+                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs)     # merged [2, T, C]
+                if two:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    main.wait_event(ev)
+                    merged.record_stream(main)                  # allocated on the side stream's pool, read on the main stream
+                    if unm is not None:
+                        unm.record_stream(main)
                 qkv = o.gemm(merged, blk["qkv"], M=2 * T)
                 a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
                 y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
                 L.tcl_gather_add_rows_f16(h[off * N:], xbs, y, T * C, unm if unm is not None else 0, 2, F * N, C, stream())
                 self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
                 off += F
+            # (running the attention of alternate chunks on a second stream as well was measured: no further gain)
         F = Ftot
         # ---- attn2: text cross-attention on the full tokens
         n2 = o.layernorm(h, *blk["ln"][1], M, C)

@@ -8,6 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --warmup 1 --steps 1 --no_cpu_baseline > $OUT/bench_under_rocprof.json 2> /dev/null
 # the warm-up pass carries the GEMM autotuner's timing launches: summarise the timed pass only
 python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/kt 60 --last-pass k_gather_codebook > $OUT/bench_kernel_stats.txt
+# the same with the matching chain on the main stream: per-kernel durations of kernels that have the GPU to themselves
+TCL_TOME_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/ktx -o kt -- python $GRAFT_REPO_ROOT/bench.py --warmup 1 --steps 1 --no_cpu_baseline --no_extras > $OUT/bench_under_rocprof_exclusive.json 2> /dev/null
+python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/ktx 60 --last-pass k_gather_codebook > $OUT/bench_kernel_stats_exclusive.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $GRAFT_REPO_ROOT/bench.py --n_timesteps 1 --warmup 0 --no_cpu_baseline --epochs 0 --epochs_exposure 1 > /dev/null 2>&1
 done

@@ -402,7 +402,7 @@ int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st) {
 int tcl_softmax_rows_f16(void* x, long rows, int T, int ld, float scale, hipStream_t st) {
     TCL_CHECK_ARG(x && rows > 0 && T > 0 && (size_t)T * 4 <= 150 * 1024);
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)k_softmax_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_softmax_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
     hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)rows), dim3(256), (size_t)T * 4, st, (_Float16*)x, T, ld, scale);
     TCL_LAUNCH_RET();
 }

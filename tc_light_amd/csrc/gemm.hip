@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
                 else {                                                                                                        \
                     int iy_ = a_oy[i] + tdy_, ix_ = a_ox[i] + tdx_;                                                           \
                     if (iy_ >= 0 && iy_ < cp.Hup && ix_ >= 0 && ix_ < cp.Wup) {                                               \
-                        if (cp.Hup != cp.Hin) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
+                        if (cp.Hup != cp.Hin || cp.Wup != cp.Win) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
                         v_ = *(const u32x4*)(A + a_off[i] + ((long)iy_ * cp.Win + ix_) * cp.Cin + c0_ + kc8);                 \
                     }                                                                                                         \
                 }                                                                                                             \
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
                 else {                                                                                                        \
                     int iy_ = a_oy[i] + tdy_, ix_ = a_ox[i] + tdx_;                                                           \
                     if (iy_ >= 0 && iy_ < cp.Hup && ix_ >= 0 && ix_ < cp.Wup) {                                               \
-                        if (cp.Hup != cp.Hin) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
+                        if (cp.Hup != cp.Hin || cp.Wup != cp.Win) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
                         src_ = A + a_off[i] + ((long)iy_ * cp.Win + ix_) * cp.Cin + c0_ + csrc;                               \
                     }                                                                                                         \
                 }                                                                                                             \
@@ -432,7 +432,7 @@ static int launch_gemm_dma(const _Float16* A, const _Float16* W, const _Float16*
     const int tm = cdiv(M, BM), tn = cdiv(N, BN), nk = K / 32;
     const size_t ops = (size_t)STAGES * (BM + BN) * 64, cs = (size_t)BM * (BN + 8) * 2, lds = ops > cs ? ops : cs;
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm_dma<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_dma<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     if (splits > nk / 4) splits = nk / 4 > 0 ? nk / 4 : 1;
     while (splits > 1 && (!g_ws || (size_t)splits * M * N * 4 > g_ws_bytes)) --splits;
     if (act == 2) splits = 1;
@@ -470,7 +470,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
     const size_t lds = (size_t)(BM + BN) * LDS_STRIDE * 2;
     static_assert((size_t)BM * (BN + 8) * 2 <= (size_t)(BM + BN) * LDS_STRIDE * 2, "C staging must fit");
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm<BM, BN, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     // small-M / deep-K problems (the 1280-channel levels, yt-plane chunks) leave most of the 256 CUs idle: split K so that
     // ~2 blocks per CU exist, partials in f32, deterministic second pass.
     const int nk = K / BK;
@@ -589,7 +589,7 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
         if (N % 256 == 0) { if (cdiv(M, 256) * (N / 256) >= 96) cand[nc++] = 7; if (cdiv(M, 128) * (N / 256) >= 96) cand[nc++] = 8; }
     }
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     // two interleaved rounds, minimum per candidate: one disturbed measurement (clock ramp, a profiler attached) must not pick the tile
     float t_ms[9]; bool ok[9];
     for (int i = 0; i < nc; ++i) {
@@ -600,17 +600,17 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     for (int round = 0; round < 2; ++round)
         for (int i = 0; i < nc; ++i) {
             if (!ok[i]) continue;
-            hipEventRecord(e0, st);
+            (void)hipEventRecord(e0, st);
             for (int r = 0; r < 3; ++r) run_cfg(cand[i], splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-            hipEventRecord(e1, st);
-            hipEventSynchronize(e1);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             t_ms[i] = fminf(t_ms[i], ms);
         }
     int best = fallback; float best_ms = 1e30f;
     for (int i = 0; i < nc; ++i) if (ok[i] && t_ms[i] < best_ms) { best_ms = t_ms[i]; best = cand[i]; }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     g_tune_cache[key] = best;
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;      // the timed runs already produced C
 }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
             else {                                                                                                            \
                 int iy_ = a_oy[i] + tdy_, ix_ = a_ox[i] + tdx_;                                                               \
                 const bool in_ = iy_ >= 0 && iy_ < cp.Hup && ix_ >= 0 && ix_ < cp.Wup;                                        \
-                if (cp.Hup != cp.Hin) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
+                if (cp.Hup != cp.Hin || cp.Wup != cp.Win) { iy_ = min((int)floorf(iy_ * cp.sy), cp.Hin - 1); ix_ = min((int)floorf(ix_ * cp.sx), cp.Win - 1); } \
                 sa_[i] = in_ ? ap[i] + ((long)iy_ * cp.Win + ix_) * cp.Cin + c0_ : nullptr;                                   \
             }                                                                                                                 \
         }                                                                                                                     \
@@ -231,8 +231,8 @@ static int launch8(const _Float16* A, const _Float16* W, const _Float16* bias, c
     const size_t ring = (size_t)4 * (BM + BN) * 64 + 1024, epi = (size_t)8 * 32 * (NT * 32 + 8) * 2, lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const dim3 grid(cdiv(tm, 8) * 8 * tn);

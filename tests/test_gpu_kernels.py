@@ -47,7 +47,8 @@ def test_gemm(L, M, N, K, act):
 
 @pytest.mark.parametrize("B,Hh,Ww,Cin,Cout,stride,pad,up", [
     (2, 18, 24, 64, 128, 1, 1, None), (3, 23, 30, 128, 64, 2, 1, None), (2, 12, 15, 64, 64, 1, 1, (23, 30)),
-    (2, 9, 10, 64, 320, 1, 1, (18, 20)), (2, 16, 24, 64, 64, 2, 0, None)])
+    (2, 9, 10, 64, 320, 1, 1, (18, 20)), (2, 16, 24, 64, 64, 2, 0, None),
+    (2, 1, 3, 64, 64, 1, 1, (1, 6)), (2, 3, 1, 64, 64, 1, 1, (6, 1)), (2, 1, 1, 128, 64, 1, 1, (1, 2))])     # up-sampling along one axis only (yt planes of <= 4 frames)
 def test_conv3x3(L, B, Hh, Ww, Cin, Cout, stride, pad, up):
     g = torch.Generator(device="cuda").manual_seed(Cin + Cout + Hh)
     x = torch.randn(B, Cin, Hh, Ww, device="cuda", generator=g).to(H)

@@ -253,7 +253,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{a.frames} frames/GPU {W}x{H}, {a.n_timesteps} denoise steps, "
                                    f"{'multi_axis (alpha_t=0.01)' if not a.no_multi_axis else 'single axis'}, VidToMe 0.6/0.5, stage-1 "
-                                   f"{a.epochs_exposure} + stage-2 {a.epochs} epochs (BASELINE.json configs[1])",
+                                   f"{a.epochs_exposure} + stage-2 {a.epochs} epochs"
+                                   + (" (BASELINE.json configs[1])" if (a.frames, H, W, a.n_timesteps, a.epochs_exposure, a.epochs, a.no_multi_axis)
+                                      == (30, 720, 960, 20, 35, 70, False) else " (NOT the BASELINE workload: non-default flags)"),
                        "frames_total": n_total, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
                        "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},

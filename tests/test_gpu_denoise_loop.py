@@ -5,8 +5,8 @@ tests/test_oracle_path1.py), oracle scheduler, the same chunk draws and the same
 VidToMe is switched off here (the merge decisions are discrete and are covered, with injected indices, by test_gpu_unet.py); what
 this test pins is the orchestration around the UNet.  Per step the oracle is fed the latents the engine had at that step and must
 reproduce the fused noise prediction handed to the scheduler: rel-L2 <= 1e-2 (f16 engine vs fp32 oracle through ~700 kernels, as in
-test_gpu_unet.py; measured 3.3e-3 / 1.5e-3).  The final latents of the free-running oracle loop are compared too: rel-L2 <= 1e-2,
-measured 1.7e-3.  (This test found the one-axis up-sampling bug of the implicit conv: a yt plane of <= 4 frames goes 1x1 -> 1x2.)"""
+test_gpu_unet.py; measured 3.3e-3 / 1.5e-3), and the latents after each step must equal the oracle scheduler's update of the same
+inputs (rel-L2 <= 2e-3: f16 storage).  (This test found the one-axis up-sampling bug of the implicit conv: a yt plane of <= 4 frames goes 1x1 -> 1x2.)"""
 import pytest
 import torch
 
@@ -54,6 +54,12 @@ def test_ddim_sample_multi_axis_vs_oracle():
     x_hip = g.ddim_sample(x0.clone(), conds.cuda(), conds_t.cuda(), cc.cuda()).float().cpu()
     torch.cuda.synchronize()
     assert torch.isfinite(x_hip).all() and len(zs) == 2 and zs[-1] is None
+    # the same run with every chunk in a UNet pass of its own (`max_tokens_per_pass` forces one chunk per group): identical draws
+    # and noise, so it may differ only through the row count of the batched kernels (GroupNorm partial sums, K-split rule)
+    g1 = Generator(eng, None, dict(cfg, max_tokens_per_pass=1))
+    g1.prepare_data(torch.zeros(n, 3, 8 * hh, 8 * ww, device="cuda"))
+    x_one = g1.ddim_sample(x0.clone(), conds.cuda(), conds_t.cuda(), cc.cuda()).float().cpu()
+    assert rel(x_one, x_hip) < 2e-3
 
     # ---- the same loop on the CPU oracle
     c = g.cfg
@@ -74,15 +80,15 @@ def test_ddim_sample_multi_axis_vs_oracle():
         return OP.temporal_denoise(xc, ccf, alphas[i], noises, c.win_size_t, [torch.as_tensor(ch) for ch in yt_chunks],
                                    lambda xt, ct, ch, sl: pred(torch.cat([xt, ct], 1), text_t, float(t)))[1]
 
+    nxt = [seen[1][0], x_hip]                                  # latents the engine had after each step
     for i, t in enumerate(osch.timesteps.tolist()):
         xy_chunks, yt_chunks = xy_s.get_chunks(n), yt_s.get_chunks(ww)
-        # (a) teacher-forced: the engine's own latents at this step -> the fused prediction it handed to the scheduler
+        # (a) the engine's own latents at this step -> the fused prediction it handed to the scheduler
         r = rel(seen[i][1], fused_eps(seen[i][0], xy_chunks, yt_chunks, i, t))
         print(f"[denoise loop parity] step {i}: fused eps rel-L2 = {r:.3e}")
         assert r < 1e-2, (i, r)
-        # (b) free-running oracle loop
+        # (b) the scheduler update the loop applied to it (multistep state carried by the oracle scheduler)
         z = zs[i] if zs[i] is not None else torch.zeros_like(x)
-        x = osch.step(fused_eps(x, xy_chunks, yt_chunks, i, t), x, z).half().float()
-    r = rel(x_hip, x)
-    print(f"[denoise loop parity] final latents after 2 steps (6 frames, 2 overlapping windows): rel-L2 = {r:.3e}")
-    assert r < 1e-2, r
+        r = rel(nxt[i], osch.step(seen[i][1], seen[i][0], z))
+        print(f"[denoise loop parity] step {i}: latents after the SDE step rel-L2 = {r:.3e}")
+        assert r < 2e-3, (i, r)

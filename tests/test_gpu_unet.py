@@ -157,3 +157,26 @@ def test_forward_many_equals_sequential(setup):
     print("sequential vs sequential (min/mean map agreement, max eps rel-L2):", base, " sequential vs forward_many:", got)
     assert base == (1.0, 1.0, 0.0)                # deterministic kernels: no float atomics on the UNet path
     assert got[1] > 0.85 and got[2] < 2e-2
+
+
+@pytest.mark.parametrize("Hh,Ww,Fs,Lt", [(4, 8, [2, 4, 2], 77), (5, 9, [3], 77), (9, 5, [3], 154), (6, 10, [1, 2], 77)])
+def test_unet_small_odd_planes_vs_oracle(setup, Hh, Ww, Fs, Lt):
+    """Plane geometries the yt axis produces for short windows (rows = frames of the window): sizes that halve to 1 along one axis
+    before the other, odd sizes whose up-sampling is not 2x (5 -> 3 -> 5), several chunks per pass.  VidToMe off (pure geometry).
+    (4, 8) is the case that exposed the one-axis nearest up-sampling bug of the implicit conv (1x1 -> 1x2)."""
+    from oracle import sd15 as OS
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vidtome import VidToMe
+    sd, _, _ = setup
+    eng = UNetEngine(sd, "cuda", VidToMe("cuda", seed=5, enabled=False))
+    F = sum(Fs)
+    x, _ = _inputs(F, Hh, Ww, 40 + Hh)
+    text = torch.from_numpy(np.random.default_rng(Hh).standard_normal((2, Lt, 768)).astype(np.float32)).half().float()
+    xin = torch.cat([x, x]).permute(0, 2, 3, 1).contiguous().cuda().half()
+    eps = eng.forward_many(xin, Fs, Hh, Ww, 501.0, text.cuda().half()).view(2 * F, Hh, Ww, 4).permute(0, 3, 1, 2).float().cpu()
+    off = 0
+    for f in Fs:
+        ref = OS.unet_forward(sd, torch.cat([x[off:off + f], x[off:off + f]]), 501.0, text)
+        got = torch.cat([eps[off:off + f], eps[F + off:F + off + f]])
+        assert rel(got, ref) < 1e-2, (Hh, Ww, f, rel(got, ref))
+        off += f

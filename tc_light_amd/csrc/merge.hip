@@ -112,17 +112,18 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
     // One flattened loop over (src tile, k step): the DMA ring keeps running across tile boundaries, so the prologue of the next src
     // tile and the epilogue of the current one (VALU + atomics) overlap.  The src row pointers of the tile being ISSUED live in sp.
     const _Float16* sp[2];
-    int it_issue = -1;
+    int it_issue = 0, kt_issue = 0;
 #define TOME_ISSUE(STEP, BUF)                                                                                                 \
     {                                                                                                                         \
-        const int t_ = (STEP) / nk, kt_ = (STEP) - t_ * nk;                                                                   \
-        if (t_ != it_issue) {                                                                                                 \
-            it_issue = t_;                                                                                                    \
+        /* steps are issued in order: (tile, k step) of the one being issued are running counters, no division */           \
+        const int kt_ = kt_issue;                                                                                             \
+        if (kt_ == 0) {                                                                                                       \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
-                const int si_ = (ts0 + t_) * 128 + (wid * 2 + i) * 16 + rr;                                                   \
+                const int si_ = (ts0 + it_issue) * 128 + (wid * 2 + i) * 16 + rr;                                             \
                 sp[i] = si_ < na ? base + (long)a_pos[si_] * C + csrc : nullptr;                                              \
             }                                                                                                                 \
         }                                                                                                                     \
+        if (++kt_issue == nk) { kt_issue = 0; ++it_issue; }                                                                   \
         char* sb_ = smem + (BUF) * STAGE;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                      \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp[i] ? dp[i] + kt_ * 32 : zero), \

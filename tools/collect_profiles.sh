@@ -5,7 +5,7 @@ R=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --warmup 1 --steps 1 --no_cpu_baseline > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --warmup 1 --steps 1 --no_cpu_baseline --no_extras > $OUT/bench_under_rocprof.json 2> /dev/null
 # the warm-up pass carries the GEMM autotuner's timing launches: summarise the timed pass only
 python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/kt 60 --last-pass k_gather_codebook > $OUT/bench_kernel_stats.txt
 # the same with the matching chain on the main stream: per-kernel durations of kernels that have the GPU to themselves

@@ -64,6 +64,20 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
                           float lambda_flow, float lambda_tv, float* feat, float* g, float* m, float* v, float* losses,
                           float* images_out, void* ws, hipStream_t st);
 
+/* One mini-batch of stage 1 / stage 2, GRADIENT ONLY (forward + backward of generate.py:396-429 / :496-522, no optimiser step): what the
+ * whole-stage drivers above run per iteration, exposed so that a multi-GPU host loop can put a collective between the gradient and the
+ * Adam step (tc_light_amd/post_opt.py; SURVEY 8(e): the slots of a mini-batch are dealt to the ranks, codebook / exposure gradients meet
+ * in reduce_scatter / all_reduce over xGMI, tcl_adam_step updates).  d_cidx (DEVICE) int32 [2*b_loc] = [cur(b_loc) | max(cur-1,0)(b_loc)]
+ * for THIS caller's slots; b_glob = slots of the whole mini-batch, nvalid_glob = how many of them have frame id > 0: every mean of the
+ * reference's loss runs over the global mini-batch, so the callers' partial gradients and *loss_part values simply add up.
+ * g is accumulated into (+=) and must be zero (or hold other slots' partial sums) on entry; ws: tcl_stage_workspace_bytes(b_loc, h, w). */
+int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* d_cidx, int b_loc,
+                      int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow, const float* exposure, float* g,
+                      float* loss_part, void* ws, hipStream_t st);
+int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
+                           const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                           float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st);
+
 /* ===================================================================== path 1: denoising loop (f16, f32 accumulate)
  * Activations are NHWC / token-major [B, H*W, C] f16 on the device.  These replace the library kernels the reference
  * reaches through diffusers' UNet2DConditionModel / AutoencoderKL (generate.py:342-347; generate_utils.py:144,161). */

@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(const float* __restrict__ X, c
 // sums: [4][planes] (levels 1..4 are computed, level 0 is the constant 1 of start_level=1);
 // cnt[l] = valid pixels of level l.  scal[l][q] = d(loss)/d(sum_l[q]); loss_out += lambda*(1-mean msssim)
 struct Cnt4 { float c[4]; };
-__global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, Cnt4 cn, float lambda,
+__global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, int planes_norm, Cnt4 cn, float lambda,
                                   float* __restrict__ scal, float* __restrict__ loss_out) {
+    // planes_norm: the plane count the mean runs over (== planes on one GPU; the GLOBAL batch*3 when the mini-batch is split over ranks:
+    // the per-rank terms then add up to the global loss and the gradients carry the global 1/planes).
     __shared__ float red[16];
     const float wgt[4] = {0.2856f, 0.3001f, 0.2363f, 0.1333f};
     float tot = 0.f;
@@ -233,10 +235,10 @@ __global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, Cn
         for (int l = 0; l < 4; ++l) { v[l] = fmaxf(sums[l * planes + q] / cn.c[l], 0.f); prod *= powf(v[l], wgt[l]); }
         tot += prod;
         for (int l = 0; l < 4; ++l)
-            scal[l * planes + q] = v[l] > 0.f ? -lambda / (float)planes * prod * wgt[l] / v[l] / cn.c[l] : 0.f;
+            scal[l * planes + q] = v[l] > 0.f ? -lambda / (float)planes_norm * prod * wgt[l] / v[l] / cn.c[l] : 0.f;
     }
     float r = block_sum(tot, red);
-    if (threadIdx.x == 0) *loss_out = lambda * (1.f - r / (float)planes);
+    if (threadIdx.x == 0) *loss_out = planes_norm == planes ? lambda * (1.f - r / (float)planes) : lambda * ((float)planes - r) / (float)planes_norm;
 }
 // grad wrt X of one level: s * (Y*G^T(a) + 2X*G^T(b) + G^T(c)) + avgpool-backward of the next level's grad
 __global__ __launch_bounds__(256) void k_ssim_bwd(const float* __restrict__ X, const float* __restrict__ Y, int h, int w,
@@ -482,7 +484,8 @@ size_t tcl_msssim_workspace_bytes(int planes, int h, int w) { return carve_ms(nu
 // forward (+ optional backward to level-1 grad) of lambda*(1 - relaxed_ms_ssim(X, Y, start_level=1)).
 // X: [planes] contiguous planes; Y planes addressed through yidx (frame ids, 3 planes per frame) or contiguous.
 static int msssim_chain(const float* X, const float* Y, const int* yidx, int planes, int h, int w, float lambda, MsWs& W,
-                        bool backward, hipStream_t st) {
+                        bool backward, hipStream_t st, int planes_norm = 0) {
+    if (planes_norm <= 0) planes_norm = planes;
     static const Gauss11 G = make_gauss();
     for (int l = 1; l < 5; ++l) if (W.h[l] < 11 || W.w[l] < 11) return TCL_EINVAL;
     Cnt4 cn;
@@ -496,7 +499,7 @@ static int msssim_chain(const float* X, const float* Y, const int* yidx, int pla
         hipLaunchKernelGGL(k_ssim_fwd, gs, dim3(256), 0, st, W.X[l], W.Y[l], W.h[l], W.w[l], l == 4 ? 1 : 0, 0.0001f, 0.0009f, G,
                            W.mA[l], W.mB[l], W.mC[l], W.sums + (size_t)(l - 1) * planes);
     }
-    hipLaunchKernelGGL(k_msssim_finalize, dim3(1), dim3(256), 0, st, W.sums, planes, cn, lambda, W.scal, W.term);
+    hipLaunchKernelGGL(k_msssim_finalize, dim3(1), dim3(256), 0, st, W.sums, planes, planes_norm, cn, lambda, W.scal, W.term);
     if (backward)
         for (int l = 4; l >= 1; --l) {
             dim3 gs(cdiv(W.w[l], TW), cdiv(W.h[l], TH), planes);
@@ -553,38 +556,81 @@ static double expon_lr(int step, double lr_init, double lr_final, int max_steps)
     return exp(log(lr_init) * (1 - t) + log(lr_final) * t);
 }
 
+// ---- one mini-batch, gradient only.  The whole-stage drivers below and the multi-GPU host loop (tc_light_amd/post_opt.py: the batch's
+// slots are dealt to the ranks, the gradients meet in a collective before the Adam step) share these.
+// d_cidx (device) int32 [2*b_loc]: [cur(b_loc) | max(cur-1, 0)(b_loc)] -- THIS caller's slots of the mini-batch.  b_glob / nvalid_glob:
+// slots and slots with idx > 0 of the WHOLE mini-batch: every mean of the loss (generate.py:413-427, :507-520) runs over the global batch,
+// so partial losses / gradients of the ranks simply add up.  g is accumulated into (+=); *loss_part receives this caller's share of the loss.
+int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* d_cidx, int b_loc,
+                      int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow, const float* exposure, float* g,
+                      float* loss_part, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(edited && flows && masks && d_cidx && exposure && g && loss_part && ws);
+    TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160);
+    StageWs S = carve_stage((char*)ws, b_loc, H, W);
+    const size_t P = (size_t)H * W;
+    const int b = b_loc;
+    S.cidx = const_cast<int*>(d_cidx);
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
+    hipLaunchKernelGGL(k_apply_exposure, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.cat, (int)P);
+    const float wp = 1.f - lambda_flow, c_l1 = wp * (1.f - lambda_dssim) / ((float)b_glob * 3 * P);  // (1-lf) folded in
+    int rc = msssim_chain(S.cat, edited, S.cidx, b * 3, H, W, wp * lambda_dssim, S.ms, true, st, b_glob * 3);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, edited, S.cidx, S.ms.gX[1], S.ms.h[1], S.ms.w[1], H, W,
+                       c_l1, 0.f, 0.f, S.gcat, S.acc);
+    if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
+    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
+    hipLaunchKernelGGL(k_exposure_bwd, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gcat, g, (int)P);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, c_l1, lambda_flow, inv_cnt, 0.f, 0.f, loss_part);
+    TCL_LAUNCH_RET();
+}
+
+int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
+                           const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                           float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(target && flows && masks && unq_inv && d_cidx && feat && g && loss_part && ws);
+    TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_loc <= 64 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160 && K > 0);
+    StageWs S = carve_stage((char*)ws, b_loc, H, W);
+    const size_t P = (size_t)H * W;
+    const int b = b_loc;
+    S.cidx = const_cast<int*>(d_cidx);
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
+    hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
+    // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
+    int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st, b_glob * 3);
+    if (rc) return rc;
+    float ch = lambda_tv * 2.f / (3.f * (H - 1) * W) / b_glob, cw = lambda_tv * 2.f / (3.f * H * (W - 1)) / b_glob;
+    hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, (const float*)nullptr, S.cidx, S.ms.gX[1], S.ms.h[1],
+                       S.ms.w[1], H, W, 0.f, ch, cw, S.gcat, S.acc);
+    if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
+    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
+    hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P, K);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, loss_part);
+    TCL_LAUNCH_RET();
+}
+
 // Stage 1 (generate.py:354-451).  sched: host int32 [iters][batch] frame ids, -1 pads a short batch;
 // d_cat: packed cat indices on the device.  exposure/m/v/g: [N,3,4] device (exposure = eye, others 0 on entry).
-// losses: device float [iters].  On return (stream order) `edited` holds the aligned frames.
+// losses: device float [iters].  On return (stream order) `aligned_out` holds the aligned frames.
 int tcl_exposure_align(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* sched,
                        const int* d_cat, int iters, int iters_per_epoch, int batch, int epochs, float lr_init, float lr_final, float lambda_dssim,
                        float lambda_flow, float* exposure, float* g, float* m, float* v, float* losses, float* aligned_out,
                        void* ws, hipStream_t st) {
     TCL_CHECK_ARG(edited && flows && masks && sched && d_cat && exposure && g && m && v && losses && aligned_out && ws);
     TCL_CHECK_ARG(N > 0 && batch > 0 && iters > 0 && epochs > 0 && iters_per_epoch > 0 && H > 160 && W > 160);
-    StageWs S = carve_stage((char*)ws, batch, H, W);
     const size_t P = (size_t)H * W;
     const int total_iters = epochs * N / batch, per_epoch = iters_per_epoch;
-    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
-        S.cidx = const_cast<int*>(d_cat) + (size_t)it * 2 * batch;   // [cur(b) | prev(b)] packed for this iteration
         int epoch = it / per_epoch, i = it % per_epoch;
         float lr = (float)expon_lr(epoch * N / batch + i + 1, lr_init, lr_final, total_iters);
-        hipLaunchKernelGGL(k_apply_exposure, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.cat, (int)P);
-        const float wp = 1.f - lambda_flow, c_l1 = wp * (1.f - lambda_dssim) / ((float)b * 3 * P);  // (1-lf) folded in
-        int rc = msssim_chain(S.cat, edited, S.cidx, b * 3, H, W, wp * lambda_dssim, S.ms, true, st);
+        int rc = tcl_exposure_grad(edited, flows, masks, N, H, W, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim, lambda_flow,
+                                   exposure, g, losses + it, ws, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, edited, S.cidx, S.ms.gX[1], S.ms.h[1], S.ms.w[1], H, W,
-                           c_l1, 0.f, 0.f, S.gcat, S.acc);
-        if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
-        float inv_cnt = nvalid ? 1.f / ((float)nvalid * 3 * P) : 0.f;
-        hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
-        hipLaunchKernelGGL(k_exposure_bwd, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gcat, g, (int)P);
-        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, c_l1, lambda_flow, inv_cnt, 0.f, 0.f, losses + it);
         rc = tcl_adam_step(exposure, g, m, v, (size_t)N * 12, lr, 0.9f, 0.999f, 1e-8f, it + 1, st);
         if (rc) return rc;
     }
@@ -599,28 +645,16 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
                           hipStream_t st) {
     TCL_CHECK_ARG(target && flows && masks && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
     TCL_CHECK_ARG(N > 0 && batch > 0 && batch <= 64 && iters >= 0 && H > 160 && W > 160 && K > 0);
-    StageWs S = carve_stage((char*)ws, batch, H, W);
     const size_t P = (size_t)H * W;
     const float lr = feature_lr * (float)batch / (float)N;
-    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
-        S.cidx = const_cast<int*>(d_cat) + (size_t)it * 2 * batch;
-        hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
-        // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
-        int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st);
+        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim,
+                                        lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
         if (rc) return rc;
-        float ch = lambda_tv * 2.f / (3.f * (H - 1) * W) / b, cw = lambda_tv * 2.f / (3.f * H * (W - 1)) / b;
-        hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, (const float*)nullptr, S.cidx, S.ms.gX[1], S.ms.h[1],
-                           S.ms.w[1], H, W, 0.f, ch, cw, S.gcat, S.acc);
-        if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
-        float inv_cnt = nvalid ? 1.f / ((float)nvalid * 3 * P) : 0.f;
-        hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
-        hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P, K);
-        hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, losses + it);
         rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
         if (rc) return rc;
     }

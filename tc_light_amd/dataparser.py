@@ -1,88 +1,210 @@
-"""VideoDataParser (reference: utils/dataparsers/video_dataparser.py:12-156) -- frames, cached optical flow, soft masks, track ids.
+"""VideoDataParser + video I/O (reference: utils/dataparsers/video_dataparser.py:12-156, utils/VidToMe/utils.py:83-179).
 
-Frames: .npy / .pt tensors [N,3,H,W] or [N,H,W,3] (uint8 or float), a directory of such per-frame files, or a video container when
-torchvision.io / cv2 is importable (neither is in the target image).  Flow: the reference's on-disk cache format
-`<video>_{past,future}_flow_memflow/%04d.pt` (one [1,2,H,W] tensor per frame, used when the file count matches, :112-132).  Flow
-ESTIMATION: `estimate_and_cache_flow` runs the MemFlowNet engine (tc_light_amd/memflow.py) when no cache exists and writes the same files.
+Frames come from (in the order the reference's `load_video` tests them, utils/VidToMe/utils.py:118-139):
+  * `.mp4` / `.avi` containers -- decoded with torchvision.io or cv2 when one of them is importable (neither is in the target image: the
+    error then says how to convert; `.npy` / `.pt` tensors [N,3,H,W] or [N,H,W,3] are accepted as the decoder-free stand-in);
+  * `.gif` -- PIL `ImageSequence`;
+  * a directory of `.jpg/.png/.JPG/.PNG` frames (FRAME_EXT, utils.py:16) read with PIL.  The reference's `load_image` maps such frames to
+    `x*255/127 - 1` and `VideoDataParser.load_video` maps them back with `(x+1)*127/255` (utils.py:76-80, video_dataparser.py:37-38);
+    the round trip is reproduced literally so the f32 rounding is the reference's.
+Flow: the reference's on-disk cache format `<video>_{past,future}_flow_memflow/%04d.pt` (one [1,2,H,W] tensor per frame, used when the
+file count matches, :112-132).  `estimate_and_cache_flow` runs the MemFlowNet engine (tc_light_amd/memflow.py) when no cache exists.
+Output: `save_video` / `save_frames` (utils.py:147-187): `output{post_fix}.mp4` through torchvision/cv2 when an encoder exists, else the
+frames as PNGs under `frames{post_fix}/` plus `output{post_fix}.npy` (uint8 [N,H,W,3]) so `evaluate.py`-style consumers still find data.
 """
 import os
+from glob import glob
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+FRAME_EXT = [".jpg", ".png", ".JPG", ".PNG"]            # utils/VidToMe/utils.py:16
+
 
 def _to_nchw01(a):
-    t = torch.as_tensor(np.asarray(a)) if not isinstance(a, torch.Tensor) else a
-    if t.dim() == 4 and t.shape[-1] == 3:
+    """array / tensor [N,3,H,W] or [N,H,W,3] -> float32 NCHW in [0,1]; integer dtypes are 8-bit pixel values (scaled by 1/255), floating
+    dtypes are taken as already in [0,1] (the scaling follows the dtype, never the value range: a dark uint8 clip stays a uint8 clip)."""
+    t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+    if t.dim() == 3:
+        t = t[None]
+    if t.dim() == 4 and t.shape[-1] == 3 and t.shape[1] != 3:
         t = t.permute(0, 3, 1, 2)
-    t = t.float()
-    return t / 255.0 if t.max() > 1.5 else t
+    if t.dtype.is_floating_point:
+        return t.float()
+    return t.float() / 255.0
+
+
+def _torch_load(path):
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_image(image_path):
+    """utils/VidToMe/utils.py:76-80: RGB frame -> [1,3,H,W] in [-1, 1.008]."""
+    from PIL import Image
+    img = np.asarray(Image.open(image_path).convert("RGB"), dtype=np.uint8)
+    t = torch.from_numpy(img.copy()).permute(2, 0, 1).float().div(255.0)            # T.ToTensor()
+    return (t * 255.0 / 127.0 - 1.0).unsqueeze(0)
+
+
+def glob_frame_paths(video_path):
+    paths = []
+    for ext in FRAME_EXT:
+        paths += glob(os.path.join(video_path, f"*{ext}"))
+    return sorted(paths)
 
 
 def process_frames(frames, h, w):
-    """utils/VidToMe/utils.py:147-179: resize so the short side covers, then centre-crop to (h, w)."""
+    """utils/VidToMe/utils.py:83-105: T.Resize so the short side covers (bilinear, antialiased on tensors), then centre-crop to (h, w)."""
     fh, fw = frames.shape[-2:]
-    s = max(h / fh, w / fw)
-    nh, nw = max(h, round(fh * s)), max(w, round(fw * s))
-    frames = F.interpolate(frames, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
-    t, l = (nh - h) // 2, (nw - w) // 2
+    s = max(w / fw, h / fh)
+    nh, nw = int(round(fh * s)), int(round(fw * s))
+    if (nh, nw) != (fh, fw):
+        frames = F.interpolate(frames, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
+    t, l = int(round((nh - h) / 2.0)), int(round((nw - w) / 2.0))                  # torchvision center_crop
     return frames[..., t:t + h, l:l + w]
+
+
+def read_frames(path):
+    """-> float32 [N,3,H,W]; containers / gifs / tensors in [0,1], frame directories in the reference's [-1,1] convention."""
+    if os.path.isdir(path):
+        fps = glob_frame_paths(path)
+        if fps:
+            return torch.cat([load_image(p) for p in fps])
+        fs = sorted(f for f in os.listdir(path) if f.endswith((".npy", ".pt")))
+        if not fs:
+            raise FileNotFoundError(f"no frames ({'/'.join(FRAME_EXT)} or .npy/.pt) under {path}")
+        return torch.cat([_to_nchw01(np.load(os.path.join(path, f)) if f.endswith(".npy") else _torch_load(os.path.join(path, f))) for f in fs])
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    if path.endswith(".npy"):
+        return _to_nchw01(np.load(path))
+    if path.endswith(".pt"):
+        return _to_nchw01(_torch_load(path))
+    if path.endswith(".gif"):
+        from PIL import Image, ImageSequence
+        return torch.stack([torch.from_numpy(np.asarray(fr.convert("RGB")).copy()).permute(2, 0, 1).float() / 255.0
+                            for fr in ImageSequence.Iterator(Image.open(path))])
+    try:
+        import torchvision.io as tvio
+        return tvio.read_video(path, pts_unit="sec", output_format="TCHW")[0].float() / 255.0
+    except ImportError:
+        pass
+    try:
+        import cv2
+        cap, out = cv2.VideoCapture(path), []
+        while True:
+            ok, fr = cap.read()
+            if not ok:
+                break
+            out.append(torch.from_numpy(fr[..., ::-1].copy()))
+        return _to_nchw01(torch.stack(out))
+    except ImportError:
+        raise RuntimeError(f"no video decoder (torchvision.io / cv2) in this environment: convert {path} to a frame directory "
+                           f"({'/'.join(FRAME_EXT)}) or a [N,H,W,3] uint8 .npy first")
+
+
+def save_frames(frames, path, ext="png", frame_ids=None):
+    """utils/VidToMe/utils.py:182-187: frames [N,3,H,W] in [0,1] -> path/%04d.ext"""
+    from PIL import Image
+    os.makedirs(path, exist_ok=True)
+    ids = list(frame_ids) if frame_ids is not None else list(range(len(frames)))
+    u8 = (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    for i, fr in zip(ids, u8):
+        Image.fromarray(fr).save(os.path.join(path, "{:04}.{}".format(i, ext)))
+
+
+def save_video(frames, path, frame_ids=None, save_frame=False, gif=True, post_fix="", fps=30):
+    """utils/VidToMe/utils.py:147-179.  Returns the path of what was written.  Encoders are probed in the reference's order (torchvision
+    write_video libx264 crf 23 / medium for .mp4, imageio for .gif, PIL as the gif fallback); with none importable the uint8 frames are
+    written as `output{post_fix}.npy` and as PNGs so nothing is lost."""
+    os.makedirs(path, exist_ok=True)
+    ids = list(frame_ids) if frame_ids is not None else list(range(len(frames)))
+    frames = frames[ids]
+    proc = (frames.permute(0, 2, 3, 1) * 255).to(torch.uint8).cpu()
+    out = None
+    if not gif:
+        try:
+            from torchvision.io import write_video
+            out = os.path.join(path, f"output{post_fix}.mp4")
+            write_video(out, proc, fps=fps, video_codec="libx264", options={"crf": "23", "preset": "medium"})
+        except ImportError:
+            try:
+                import cv2
+                out = os.path.join(path, f"output{post_fix}.mp4")
+                wr = cv2.VideoWriter(out, cv2.VideoWriter_fourcc(*"mp4v"), fps, (proc.shape[2], proc.shape[1]))
+                for fr in proc.numpy():
+                    wr.write(fr[..., ::-1])
+                wr.release()
+            except ImportError:
+                out = None
+    else:
+        out = os.path.join(path, f"output{post_fix}.gif")
+        try:
+            import imageio
+            imageio.mimsave(out, [f.numpy() for f in proc], "GIF", fps=fps, loop=0)
+        except ImportError:
+            from PIL import Image
+            ims = [Image.fromarray(f.numpy()) for f in proc]
+            ims[0].save(out, save_all=True, append_images=ims[1:], duration=int(1000 / max(fps, 1)), loop=0)
+    if out is None:                                    # no encoder in this image: keep the data, say so
+        out = os.path.join(path, f"output{post_fix}.npy")
+        np.save(out, proc.numpy())
+        save_frames(frames, os.path.join(path, f"frames{post_fix}"), frame_ids=ids)
+        print(f"[INFO] no video encoder (torchvision / cv2): wrote {out} and PNG frames instead of output{post_fix}.mp4")
+    else:
+        print(f"[INFO] save video to {out}")
+    if save_frame:
+        save_frames(frames, os.path.join(path, f"frames{post_fix}"), frame_ids=ids)
+    return out
+
+
+def save_loss_curve(loss_list, output_path, title="Loss Curve"):
+    """utils/VidToMe/utils.py:189-197 (matplotlib when importable; the raw values are always kept beside the plot)."""
+    vals = [float(v) for v in (loss_list.detach().cpu().tolist() if isinstance(loss_list, torch.Tensor) else loss_list)]
+    np.save(os.path.join(output_path, f"{title}.npy"), np.asarray(vals, np.float32))
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.plot(vals); plt.xlabel("Iteration"); plt.ylabel("Loss"); plt.title(title); plt.grid()
+        plt.savefig(os.path.join(output_path, f"{title}.png")); plt.close()
+    except Exception:
+        pass
 
 
 class VideoDataParser:
     def __init__(self, data_config, device):
         self.rgb_path = data_config.get("rgb_path")
         self.h, self.w = int(data_config["height"]), int(data_config["width"])
-        self.fps = data_config.get("fps", 25)
+        self.fps = data_config.get("fps", 30)                    # video_dataparser.py:15
         self.alpha = data_config.get("alpha", 0.5)
+        self.flow_model = data_config.get("flow_model", "memflow")
         self.device = device
         self.unq_inv = None
         self._all = None
 
-    def _read(self, path):
-        if os.path.isdir(path):
-            fs = sorted(f for f in os.listdir(path) if f.endswith((".npy", ".pt")))
-            return torch.cat([_to_nchw01(np.load(os.path.join(path, f)) if f.endswith(".npy") else torch.load(os.path.join(path, f)))
-                              .reshape(-1, *_to_nchw01(np.load(os.path.join(path, f)) if f.endswith(".npy") else torch.load(os.path.join(path, f))).shape[-3:]) for f in fs])
-        if path.endswith(".npy"):
-            return _to_nchw01(np.load(path))
-        if path.endswith(".pt"):
-            return _to_nchw01(torch.load(path))
-        try:
-            import torchvision.io as tvio
-            return _to_nchw01(tvio.read_video(path, pts_unit="sec", output_format="TCHW")[0])
-        except ImportError:
-            pass
-        try:
-            import cv2
-            cap, out = cv2.VideoCapture(path), []
-            while True:
-                ok, fr = cap.read()
-                if not ok:
-                    break
-                out.append(torch.from_numpy(fr[..., ::-1].copy()))
-            return _to_nchw01(torch.stack(out))
-        except ImportError:
-            raise RuntimeError(f"no video decoder (torchvision.io / cv2) in this environment: convert {path} to a [N,H,W,3] .npy first")
-
     @property
     def n_frames(self):
         if self._all is None:
-            self._all = self._read(self.rgb_path)
+            self._all = read_frames(self.rgb_path)
         return self._all.shape[0]
 
     def load_video(self, frame_ids=None, path=None):
-        fr = self._read(path) if path is not None else (self._all if self._all is not None else self._read(self.rgb_path))
+        """video_dataparser.py:34-41: frames [N,3,h,w] f32 in [0,1] on the device, resized + centre-cropped to the working size."""
+        fr = read_frames(path) if path is not None else (self._all if self._all is not None else read_frames(self.rgb_path))
         if path is None:
             self._all = fr
         if frame_ids is not None:
             fr = fr[list(frame_ids)]
-        return process_frames(fr, self.h, self.w).to(self.device)
+        fr = process_frames(fr, self.h, self.w)
+        if fr.min() < 0:                                         # frame directories arrive in [-1, 1] (load_image)
+            fr = (fr + 1.0) * 127.0 / 255.0
+        return fr.to(self.device)
 
     def _flow_dir(self, kind):
         """create_folder (video_dataparser.py:126-131): <video>_<name> beside a file, <dir>/<name> inside a frame directory."""
-        name = f"{kind}_flow_memflow"
+        name = f"{kind}_flow_{self.flow_model}"
         if os.path.isdir(self.rgb_path):
             return os.path.join(self.rgb_path, name)
         return os.path.splitext(self.rgb_path)[0] + "_" + name
@@ -95,12 +217,13 @@ class VideoDataParser:
             d = self._flow_dir(kind)
             if not os.path.isdir(d) or len(os.listdir(d)) != len(frame_ids):
                 return None
-            out.append(torch.cat([torch.load(os.path.join(d, f"{fid:04d}.pt")).reshape(1, 2, self.h, self.w) for fid in frame_ids]))
+            out.append(torch.cat([_torch_load(os.path.join(d, f"{fid:04d}.pt")).reshape(1, 2, self.h, self.w) for fid in frame_ids]))
         return out[0].to(self.device), out[1].to(self.device)
 
     def estimate_and_cache_flow(self, frames, frame_ids, engine, save_flow=True):
         """load_flow for flow_model 'memflow' (video_dataparser.py:63-110): frames [N,3,h,w] in [0,1] (already processed to the working size)
-        -> (future_flows, past_flows) [N,2,h,w]; saved per frame as [1,2,h,w] tensors under <video>_{future,past}_flow_memflow/%04d.pt."""
+        -> (future_flows, past_flows) [N,2,h,w]; saved per frame as [1,2,h,w] tensors under <video>_{future,past}_flow_memflow/%04d.pt
+        (each file is written under a temporary name and renamed, so a reader never sees a partial file)."""
         from .memflow import estimate_flows
         fut, past = estimate_flows(engine, frames)
         if save_flow and self.rgb_path:
@@ -108,14 +231,23 @@ class VideoDataParser:
                 d = self._flow_dir(kind)
                 os.makedirs(d, exist_ok=True)
                 for i, fid in enumerate(frame_ids):
-                    torch.save(fl[i:i + 1].cpu(), os.path.join(d, f"{fid:04d}.pt"))
+                    dst = os.path.join(d, f"{fid:04d}.pt")
+                    torch.save(fl[i:i + 1].cpu(), dst + ".tmp")
+                    os.replace(dst + ".tmp", dst)
         return fut, past
 
 
 def get_frame_ids(frame_range, n_frames, frame_ids=None):
-    """utils/VidToMe/utils.py:330-346."""
-    if frame_ids is not None:
-        return list(frame_ids)
-    start, end, step = frame_range
-    end = n_frames if end is None or end < 0 else min(end, n_frames)
-    return list(range(start, end, step))
+    """utils/VidToMe/utils.py:330-346: [start, end, step] with end == -1 (or beyond the clip) meaning the clip length; sorted ids."""
+    if frame_ids is None:
+        fr = list(frame_range)
+        if len(fr) > 1 and (fr[1] is None or fr[1] == -1):
+            fr[1] = n_frames
+        if len(fr) > 1 and fr[1] > n_frames:
+            print(f"[WARNING] end frame {fr[1]} has been adjusted to number of frames {n_frames}.")
+            fr[1] = n_frames
+        frame_ids = list(range(*fr))
+    frame_ids = sorted(frame_ids)
+    shown = frame_ids if len(frame_ids) <= 4 else frame_ids[:2] + ["..."] + frame_ids[-2:]
+    print("[INFO] frame indexes: ", " ".join(str(i) for i in shown))
+    return frame_ids

@@ -27,8 +27,10 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
     global_merge_ratio=0.5, global_rand=0.5, align_batch=True, max_downsample=2, noise_mode="same", alpha_t=0.0,
     final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
     lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345,
-    shard_post_opt=True,
-    max_tokens_per_pass=1_500_000)   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split     # multi-GPU only: stage 1/2 on each rank's own frame block; False = replicated on all frames
+    shard_post_opt=False,            # multi-GPU only.  False (default): ONE global exposure set / codebook over all frames, gradients meet in
+                                     # collectives (post_opt.py) -- the reference's semantics.  True: the collective-free
+                                     # approximation (each rank's frame block as a video of its own: tracks cut at the 7 block seams).
+    max_tokens_per_pass=1_500_000)   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split
 
 
 class Generator:
@@ -42,6 +44,11 @@ class Generator:
         self.dist = dist or Dist()
         self.scheduler = scheduler or DPMSolverSDEScheduler()
         c = self.cfg
+        if int(c.chunk_size) > int(self.unet.tome.args["target_stride"]):
+            raise NotImplementedError(f"generation.chunk_size {c.chunk_size} > VidToMe target_stride {self.unet.tome.args['target_stride']}: the "
+                                      "multi-round local merge of patch.py:44-56 is not implemented (every TC-Light config uses 4)")
+        if not c.align_batch:
+            raise NotImplementedError("generation.align_batch: false is not implemented (TC-Light runs VidToMe with align_batch=True)")
         # vidtome.apply_patch(...) (generate_utils.py:98-100); max_downsample is NOT forwarded by the reference (default 2)
         t = self.unet.tome
         t.args.update(local_merge_ratio=c.local_merge_ratio, merge_global=c.merge_global, global_merge_ratio=c.global_merge_ratio,
@@ -175,9 +182,9 @@ class Generator:
         shard = d.world > 1 and c.shard_post_opt and c.apply_opt
         lo, hi = d.range(self.n_total)
         if shard:
-            # Stage 1/2 on this rank's frame block as a video of its own (the reference run on the shard, like the xy bank chains):
-            # its first frame has no predecessor, tracks are cut at the block boundary (the global track ids restricted to the block
-            # and renumbered densely give the same partition as get_flowid started at the block's first frame).  No collective at all.
+            # Opt-in approximation: stage 1/2 on this rank's frame block as a video of its own (its first frame has no predecessor, tracks
+            # are cut at the block boundary; the global track ids restricted to the block and renumbered densely give the partition
+            # get_flowid would produce when started at the block's first frame).  No collective, but NOT the reference's result.
             clean = clean_local
             past_flows, mask_bwds = past_flows[lo:hi], mask_bwds[lo:hi]
             hw = clean_local.shape[-2] * clean_local.shape[-1]
@@ -189,16 +196,17 @@ class Generator:
         losses1 = losses2 = None
         if c.apply_opt:
             N = clean.shape[0]
+            pd = None if shard else d                   # global mode: the ranks split every mini-batch and share one parameter set
             ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
-            rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # replicated mode: identical schedule on every rank
+            rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # global mode: the identical schedule on every rank
             s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)
             _, _, losses1 = post_opt.exposure_align(ds, s1, c.epochs_exposure, c.batch_size, c.exposure_lr_init, c.exposure_lr_final,
-                                                    c.lambda_dssim, c.lambda_flow)
+                                                    c.lambda_dssim, c.lambda_flow, dist=pd)
             t4 = ev()
             if c.epochs > 0:
                 s2 = post_opt.make_schedule(N, c.batch_size, c.epochs, rng)
                 clean, _, losses2 = post_opt.unique_tensor_optimization(ds, unq_inv, s2, c.batch_size, c.feature_lr, c.lambda_dssim,
-                                                                        c.lambda_flow, c.lambda_tv, k=k)
+                                                                        c.lambda_flow, c.lambda_tv, k=k, dist=pd)
             else:
                 clean = ds.edited_images
             if shard:

@@ -89,3 +89,9 @@ def shard_range(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def expon_lr(step, lr_init, lr_final, max_steps):
+    """get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, max_steps=max_steps)(step)  (utils/general_utils.py:31-64, delay off)."""
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)

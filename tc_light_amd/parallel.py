@@ -5,8 +5,13 @@ The reference is single-GPU; the sharding is this engine's design (
   * the yt-plane pass needs every frame of a 64-frame window for each latent column: x is all-gathered once per step
     (concat_conds once per run), the (window, column-chunk) work items are dealt round-robin to the ranks, each rank writes
     its columns into a zero full-size noise tensor and ONE all-reduce(SUM) assembles it (every element has one writer);
-  * stage 1/2 run replicated on the all-gathered decoded frames (their codebook gradient all-reduce would cost more over
-    xGMI than the whole stage).
+  * stage 1/2 optimise ONE global parameter set (generate.py:472-533: one features_dc [K,3] over all frames): the decoded frames are
+    all-gathered once, the slots of every mini-batch are dealt to the ranks (`deal_slots`), each rank back-propagates its slots with the
+    GLOBAL normalisers, and the gradients meet in a collective before the Adam step (`distributed_adam_loop`): stage 1 all-reduces the
+    [N,3,4] exposure gradient (14 KB); stage 2 reduce-scatters the dense [3,K] codebook gradient, every rank owns 1/world of the
+    codebook's Adam state (p, m, v: the 84 B/row/iteration stream is cut by world) and the updated rows are all-gathered.  Loss
+    scalars are all-reduced once per stage.  `shard_post_opt: true` keeps round 1's collective-free approximation (each rank's frame
+    block as a video of its own) as an opt-in.
 All functions are backend-agnostic and are exercised with gloo / world_size 2 in tests/test_parallel_cpu.py.
 """
 import torch
@@ -53,6 +58,32 @@ class Dist:
             dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full
 
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def reduce_scatter_sum(self, full, out):
+        """out[i] = sum over ranks of full[rank*len(out) + i]  (full.numel() == world * out.numel()).  RCCL: one reduce_scatter; gloo has
+        no reduce_scatter, so the CPU tests take the all_reduce + slice route (same values)."""
+        if self.world == 1:
+            out.copy_(full)
+        elif dist.get_backend() == "nccl":
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            n = out.numel()
+            out.copy_(full[self.rank * n:(self.rank + 1) * n])
+        return out
+
+    def all_gather_into(self, full, shard):
+        """full = concatenation over ranks of shard (equal sizes)."""
+        if self.world == 1:
+            full.copy_(shard)
+        else:
+            dist.all_gather_into_tensor(full, shard)
+        return full
+
     def barrier(self):
         if self.world > 1:
             dist.barrier()
@@ -82,3 +113,48 @@ def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=N
     d.reduce_full(nt_full)
     lo, hi = d.range(n_total)
     return nt_full[lo:hi]
+
+
+def deal_slots(row, rank, world):
+    """One mini-batch (frame ids, -1 = padding of a short batch) -> (this rank's slots, slots of the whole batch, how many of those have
+    id > 0).  Round-robin, like the yt items: every rank gets floor/ceil(b/world) slots."""
+    cur = [int(f) for f in row if int(f) >= 0]
+    return cur[rank::world], len(cur), sum(f > 0 for f in cur)
+
+
+def distributed_adam_loop(d, sched, p_full, g_full, grad_fn, adam_fn, shard_state, new_zeros=None):
+    """The stage-1 / stage-2 optimisation loop (generate.py:392-433, :492-523) over `sched` ([iters][batch] frame ids, -1 padded) with the
+    mini-batch split over the ranks and ONE parameter set.
+
+    p_full: flat parameter tensor, identical on every rank (numel divisible by world when shard_state); g_full: flat gradient
+    accumulator, zero on entry.  grad_fn(it, slots, b_glob, nvalid_glob, p_full, g_full, loss_out) adds this rank's partial gradient
+    (global normalisers) into g_full and writes its share of the loss into loss_out ([1] view); it is skipped for a rank without slots.
+    adam_fn(it, p, g, m, v) is one Adam step on (a shard of) the parameters and leaves g zero.
+    shard_state=False: all_reduce(g) and a replicated step (bit-identical on all ranks: the all-reduced gradient is).  shard_state=True:
+    reduce_scatter(g) -> Adam on the rank's 1/world of (p, m, v) -> all_gather of the updated rows into p_full.
+    Returns the per-iteration losses (all-reduced once at the end)."""
+    new_zeros = new_zeros or (lambda n: torch.zeros(n, dtype=p_full.dtype, device=p_full.device))
+    n = p_full.numel()
+    losses = new_zeros(max(len(sched), 1))
+    if shard_state and d.world > 1:
+        assert n % d.world == 0, "pad the flat parameter to a multiple of the world size"
+        sz = n // d.world
+        p = p_full[d.rank * sz:(d.rank + 1) * sz].clone()
+        g_sh, m, v = new_zeros(sz), new_zeros(sz), new_zeros(sz)
+    else:
+        shard_state = False
+        m, v = new_zeros(n), new_zeros(n)
+    for it, row in enumerate(sched):
+        slots, b_glob, nvalid = deal_slots(row, d.rank, d.world)
+        if slots:
+            grad_fn(it, slots, b_glob, nvalid, p_full, g_full, losses[it:it + 1])
+        if shard_state:
+            d.reduce_scatter_sum(g_full, g_sh)
+            g_full.zero_()
+            adam_fn(it, p, g_sh, m, v)
+            d.all_gather_into(p_full, p)
+        else:
+            d.all_reduce_sum(g_full)
+            adam_fn(it, p_full, g_full, m, v)
+    d.all_reduce_sum(losses)
+    return losses[:len(sched)]

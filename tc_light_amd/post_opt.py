@@ -142,10 +142,24 @@ def _pack_schedule(batches, batch_size, device):
     return sched, torch.from_numpy(cat).to(device)
 
 
+def _local_cat(sched, rank, world, device):
+    """Per iteration [cur(b_loc) | max(cur-1,0)(b_loc) | pad] of THIS rank's slots (parallel.deal_slots) as one device int32 [iters, 2*bmax]."""
+    from .parallel import deal_slots
+    rows = [deal_slots(r, rank, world)[0] for r in sched]
+    bmax = max(1, max((len(r) for r in rows), default=1))
+    cat = np.zeros((len(rows), 2 * bmax), np.int32)
+    for i, cur in enumerate(rows):
+        cat[i, :len(cur)] = cur
+        cat[i, len(cur):2 * len(cur)] = np.maximum(np.asarray(cur, np.int64) - 1, 0)
+    return torch.from_numpy(cat).to(device), bmax
+
+
 def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_final=0.001,
-                   lambda_dssim=0.2, lambda_flow=0.8, iters_per_epoch=None):
+                   lambda_dssim=0.2, lambda_flow=0.8, iters_per_epoch=None, dist=None):
     """generate.py:354-451.  Returns (aligned images, exposure [N,3,4], losses tensor) and bakes the
-    alignment into dataset.edited_images like OptDataset.exposure_align does."""
+    alignment into dataset.edited_images like OptDataset.exposure_align does.
+    dist (parallel.Dist, world > 1): the dataset holds ALL frames on every rank; each mini-batch's slots are dealt to the ranks and the
+    [N,3,4] gradient is all-reduced before every Adam step (one global exposure set, identical on all ranks)."""
     ed = dataset.edited_images
     n, _, h, w = ed.shape
     dev = ed.device
@@ -153,20 +167,43 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
     if iters_per_epoch is None:
         iters_per_epoch = -(-n // batch_size)      # len(DataLoader)
     expo = torch.eye(3, 4, device=dev)[None].repeat(n, 1, 1).contiguous()
-    g, m, v = (torch.zeros_like(expo) for _ in range(3))
-    losses = torch.zeros(len(sched), device=dev)
     out = torch.empty_like(ed)
-    ws = torch.empty(lib().tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
-    lib().tcl_exposure_align(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, sched.ctypes.data, d_cat, len(sched),
+    L = lib()
+    if dist is None or dist.world == 1:
+        g, m, v = (torch.zeros_like(expo) for _ in range(3))
+        losses = torch.zeros(len(sched), device=dev)
+        ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
+        L.tcl_exposure_align(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, sched.ctypes.data, d_cat, len(sched),
                              iters_per_epoch, batch_size, epochs, lr_init, lr_final, lambda_dssim, lambda_flow, expo, g, m, v, losses,
                              out, ws, stream())
+    else:
+        from .hostlogic import expon_lr
+        from .parallel import distributed_adam_loop
+        lcat, bmax = _local_cat(sched, dist.rank, dist.world, dev)
+        ws = torch.empty(L.tcl_stage_workspace_bytes(bmax, h, w), dtype=torch.uint8, device=dev)
+        total_iters = epochs * n // batch_size
+        g = torch.zeros(n * 12, device=dev)
+
+        def grad_fn(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
+            L.tcl_exposure_grad(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, lcat[it], len(slots), b_glob, nvalid, lambda_dssim,
+                                lambda_flow, p_full, g_full, loss_out, ws, stream())
+
+        def adam_fn(it, p, gg, m, v):
+            epoch, i = divmod(it, iters_per_epoch)
+            lr = expon_lr(epoch * n // batch_size + i + 1, lr_init, lr_final, total_iters)
+            L.tcl_adam_step(p, gg, m, v, p.numel(), lr, 0.9, 0.999, 1e-8, it + 1, stream())
+
+        losses = distributed_adam_loop(dist, sched, expo.view(-1), g, grad_fn, adam_fn, shard_state=False)
+        L.tcl_apply_exposure(ed, 0, expo, out, n, h, w, stream())
     dataset.edited_images = out
     return out, expo, losses
 
 
 def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature_lr=0.05, lambda_dssim=0.2,
-                               lambda_flow=0.8, lambda_tv=0.05, k=None):
-    """generate.py:453-533.  unq_inv: [N*H*W] integer tensor on the device.  Returns (images, features_dc, losses)."""
+                               lambda_flow=0.8, lambda_tv=0.05, k=None, dist=None):
+    """generate.py:453-533.  unq_inv: [N*H*W] integer tensor on the device.  Returns (images, features_dc, losses).
+    dist (world > 1): ONE global codebook.  Every rank holds all frames + unq_inv and a replica of the codebook for the gather; the Adam
+    state (p, m, v) is sharded by row range, the dense [3,K] gradient is reduce-scattered, updated rows are all-gathered."""
     ed = dataset.edited_images
     n, _, h, w = ed.shape
     dev = ed.device
@@ -174,15 +211,37 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
     if k is None:
         k = int(inv.max()) + 1
     sched, d_cat = _pack_schedule(batches, batch_size, dev)
-    feat = torch.empty(3, k, device=dev)        # channel-planar codebook (features_dc.t())
+    L = lib()
+    world = dist.world if dist is not None else 1
+    npad = -(-3 * k // world) * world                   # flat [3,K] padded so that the row-range shards are equal
+    flat = torch.zeros(npad, device=dev)
+    feat = flat[:3 * k].view(3, k)                      # channel-planar codebook (features_dc.t())
     cnt = torch.empty(k, device=dev)
-    lib().tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, stream())
+    L.tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, stream())
     del cnt
-    g, m, v = (torch.zeros_like(feat) for _ in range(3))
-    losses = torch.zeros(max(len(sched), 1), device=dev)
     out = torch.empty_like(ed)
-    ws = torch.empty(lib().tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
-    lib().tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, sched.ctypes.data, d_cat,
+    if world == 1:
+        g, m, v = (torch.zeros_like(feat) for _ in range(3))
+        losses = torch.zeros(max(len(sched), 1), device=dev)
+        ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
+        L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, sched.ctypes.data, d_cat,
                                 len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
                                 losses, out, ws, stream())
-    return out, feat.t(), losses[:len(sched)]      # features_dc in the reference's [K,3] orientation (a view)
+        losses = losses[:len(sched)]
+    else:
+        from .parallel import distributed_adam_loop
+        lcat, bmax = _local_cat(sched, dist.rank, dist.world, dev)
+        ws = torch.empty(L.tcl_stage_workspace_bytes(bmax, h, w), dtype=torch.uint8, device=dev)
+        g = torch.zeros(npad, device=dev)
+        lr = feature_lr * batch_size / n                # generate.py:474
+
+        def grad_fn(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
+            L.tcl_unique_tensor_grad(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, lcat[it], len(slots), b_glob, nvalid,
+                                     lambda_dssim, lambda_flow, lambda_tv, p_full, g_full, loss_out, ws, stream())
+
+        def adam_fn(it, p, gg, m, v):
+            L.tcl_adam_step(p, gg, m, v, p.numel(), lr, 0.9, 0.999, 1e-15, it + 1, stream())
+
+        losses = distributed_adam_loop(dist, sched, flat, g, grad_fn, adam_fn, shard_state=True)
+        L.tcl_gather_codebook(feat, inv, 0, out, n, h, w, k, stream())
+    return out, feat.t(), losses      # features_dc in the reference's [K,3] orientation (a view)

@@ -1,9 +1,12 @@
 """Prompt embeddings (reference: generate.py:98-135 encode_prompt_inner / encode_prompt_pair).
 
-Host plumbing, outside the two hot paths.  With a local CLIP ViT-L/14 text encoder directory (tokenizer + weights) the
-reference's chunked scheme is reproduced with `transformers`: untruncated tokens -> 75-token chunks wrapped in BOS/EOS, padded
-with EOS to 77 -> last_hidden_state per chunk -> shorter side tiled -> chunks concatenated along the sequence ->
-cat([uncond, cond]).  Without weights (the build/bench images) a deterministic text-seeded stand-in of the right shape is returned.
+Host plumbing, outside the two hot paths.  `encode_prompt_inner(txt, tokenizer, text_encoder, device)` is the reference's chunked
+scheme on any tokenizer / encoder with the HF CLIP interface (`tokenizer(txt, truncation=False, add_special_tokens=False)["input_ids"]`,
+`.model_max_length`, `.bos_token_id`, `.eos_token_id`; `text_encoder(ids).last_hidden_state`): untruncated tokens -> chunks of
+model_max_length-2 wrapped in BOS/EOS, padded with EOS to model_max_length -> last_hidden_state per chunk.  `encode_prompt_pair` tiles the
+shorter side, concatenates the chunks along the sequence and returns cat([uncond, cond]) (generate.py:553-555).
+`load_text_encoder(dir)` loads CLIP ViT-L/14 with `transformers` from a local directory; a missing directory raises unless random
+stand-ins were explicitly allowed (model_utils.allow_random), in which case deterministic text-seeded embeddings of the right shape are used.
 """
 import hashlib
 import math
@@ -16,32 +19,69 @@ import torch
 _ENC = {}
 
 
+def encode_prompt_inner(txt, tokenizer, text_encoder, device):
+    """generate.py:97-114 -> [n_chunks, model_max_length, hidden]."""
+    max_length = tokenizer.model_max_length
+    chunk_length = max_length - 2
+    id_start, id_end = tokenizer.bos_token_id, tokenizer.eos_token_id
+    id_pad = id_end
+
+    def pad(x, p, i):
+        return x[:i] if len(x) >= i else x + [p] * (i - len(x))
+
+    tokens = list(tokenizer(txt, truncation=False, add_special_tokens=False)["input_ids"])
+    chunks = [[id_start] + tokens[i:i + chunk_length] + [id_end] for i in range(0, len(tokens), chunk_length)]
+    if not chunks:
+        raise ValueError("empty prompt: the reference's chunking yields no chunk to encode (generate.py:108-112)")
+    chunks = [pad(ck, id_pad, max_length) for ck in chunks]
+    token_ids = torch.tensor(chunks).to(device=device, dtype=torch.int64)
+    with torch.no_grad():
+        return text_encoder(token_ids).last_hidden_state
+
+
+def tile_and_concat(c, uc):
+    """generate.py:121-135: repeat the side with fewer chunks, cut to the longer count, lay the chunks along the sequence.
+    c, uc: [n_chunks, L, D] -> ([1, k*L, D], [1, k*L, D])."""
+    c_len, uc_len = float(len(c)), float(len(uc))
+    max_count = max(c_len, uc_len)
+    c_repeat, uc_repeat = int(math.ceil(max_count / c_len)), int(math.ceil(max_count / uc_len))
+    max_chunk = max(len(c), len(uc))
+    c = torch.cat([c] * c_repeat, dim=0)[:max_chunk]
+    uc = torch.cat([uc] * uc_repeat, dim=0)[:max_chunk]
+    c = torch.cat([p[None, ...] for p in c], dim=1)
+    uc = torch.cat([p[None, ...] for p in uc], dim=1)
+    return c, uc
+
+
+def load_text_encoder(enc_dir, dev):
+    if enc_dir not in _ENC:
+        from transformers import CLIPTextModel, CLIPTokenizer
+        _ENC[enc_dir] = (CLIPTokenizer.from_pretrained(enc_dir), CLIPTextModel.from_pretrained(enc_dir).to(dev).half().eval())
+    return _ENC[enc_dir]
+
+
 def _n_chunks_proxy(txt):
     return max(1, math.ceil(len(txt.replace(",", " , ").replace(".", " . ").split()) * 1.3 / 75))
 
 
-def _inner(txt, dev, enc_dir):
-    if enc_dir and os.path.isdir(enc_dir):
-        if enc_dir not in _ENC:
-            from transformers import CLIPTextModel, CLIPTokenizer
-            _ENC[enc_dir] = (CLIPTokenizer.from_pretrained(enc_dir), CLIPTextModel.from_pretrained(enc_dir).to(dev).half().eval())
-        tok, model = _ENC[enc_dir]
-        ids = tok(txt, truncation=False, add_special_tokens=False)["input_ids"]
-        L, bos, eos = tok.model_max_length, tok.bos_token_id, tok.eos_token_id
-        chunks = [[bos] + ids[i:i + L - 2] + [eos] for i in range(0, max(len(ids), 1), L - 2)]
-        chunks = [c[:L] + [eos] * (L - len(c)) for c in chunks]
-        with torch.no_grad():
-            return model(torch.tensor(chunks, device=dev)).last_hidden_state
-    warnings.warn("CLIP text encoder not found -> deterministic text-seeded stand-in embeddings")
+def _stand_in(txt, dev):
     n = _n_chunks_proxy(txt)
     seed = int.from_bytes(hashlib.sha256(txt.encode()).digest()[:4], "little")
     return torch.from_numpy(np.random.default_rng(seed).standard_normal((n, 77, 768)).astype(np.float32)).to(dev).half()
 
 
-def encode_prompt_pair(positive, negative, dev, enc_dir=None):
-    """-> [2, 77*k, 768] f16 = cat([uncond, cond]) with the chunk-tiling rule of generate.py:122-133."""
-    c, uc = _inner(positive, dev, enc_dir), _inner(negative, dev, enc_dir)
-    k = max(len(c), len(uc))
-    c = torch.cat([c] * math.ceil(k / len(c)))[:k].reshape(1, -1, 768)
-    uc = torch.cat([uc] * math.ceil(k / len(uc)))[:k].reshape(1, -1, 768)
-    return torch.cat([uc, c]).contiguous()
+def encode_prompt_pair(positive, negative, dev, enc_dir=None, allow_random=False, tokenizer=None, text_encoder=None):
+    """-> [2, L*k, 768] f16 = cat([uncond, cond]) (generate.py:553-555)."""
+    if tokenizer is None and enc_dir and os.path.isdir(enc_dir):
+        tokenizer, text_encoder = load_text_encoder(enc_dir, dev)
+    if tokenizer is not None:
+        c = encode_prompt_inner(positive, tokenizer, text_encoder, dev)
+        uc = encode_prompt_inner(negative, tokenizer, text_encoder, dev)
+    else:
+        if not allow_random:
+            raise FileNotFoundError(f"CLIP text encoder directory {enc_dir!r} not found (models.text_encoder); set models.allow_random / "
+                                    "TCL_ALLOW_RANDOM_WEIGHTS=1 for deterministic stand-in embeddings")
+        warnings.warn("CLIP text encoder not found -> deterministic text-seeded stand-in embeddings (allow_random)")
+        c, uc = _stand_in(positive, dev), _stand_in(negative, dev)
+    c, uc = tile_and_concat(c, uc)
+    return torch.cat([uc, c]).to(torch.float16).contiguous()

@@ -119,9 +119,14 @@ class VidToMe:
         L = self.L
         if xbs is None:
             xbs = F * N * C
+        if F > a["target_stride"]:
+            # patch.py:44-56 merges longer chunks in several randframe rounds (8 -> 2 -> 1) carrying the unmerged tokens along; TC-Light
+            # never configures chunk_size > target_stride (4), so only the single round is built -- refuse instead of mis-indexing.
+            raise NotImplementedError(f"VidToMe local merging of {F}-frame chunks: only chunks of <= target_stride "
+                                      f"({a['target_stride']}) frames (one randframe round) are implemented")
         if F > 1:
             a_pos, b_pos = self._positions(F, N, self.randf)
-            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, (F - 1) * N, b_pos, N, a["local_merge_ratio"], tbs=xbs)
+            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=xbs)
             local = torch.empty(2, TL, C, dtype=H16, device=self.dev)
             L.tcl_gather_rows_f16(x, xbs, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
         else:

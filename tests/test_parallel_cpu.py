@@ -85,3 +85,130 @@ def test_sharded_temporal_pass_world2():
             sl, nwin, cols, up, nkeep = it
             _compute_one(x, cc, (sl, nwin, cols, up, nwin), ref)     # write ALL frames, sequentially, like generate.py:265-278
         assert torch.equal(got, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Stage 1 / stage 2 with ONE global parameter set: mini-batch slots dealt to the ranks, gradients meet in a collective.
+# Stand-in compute = the CPU oracle's own loss terms evaluated on a rank's slots with the GLOBAL normalisers -- exactly the contract of
+# tcl_exposure_grad / tcl_unique_tensor_grad (include/tclight_hip.h) -- so the test pins both the choreography and the normaliser algebra
+# against the oracle's single-process loops (which are themselves pinned to the reference by tests/golden/path2.npz).
+
+def _partial_stage2(O, feats, inv_nhw, slots, b_glob, nvalid_glob, target, flows, masks, ld=0.2, lf=0.8, ltv=0.05):
+    idx = torch.tensor(slots, dtype=torch.int64)
+    n, h, w = inv_nhw.shape
+    cat_idx = torch.cat([idx, (idx - 1).clamp(min=0)])
+    cat = torch.index_select(O.sh2rgb(feats), 0, inv_nhw[cat_idx].reshape(-1)).clamp(0, 1)
+    cat = cat.reshape(len(cat_idx), h, w, 3).permute(0, 3, 1, 2)
+    images, pre = cat[:len(idx)], cat[len(idx):]
+    b = len(idx)
+    l_photo = (1.0 - O.relaxed_ms_ssim(images, target[idx], 1.0, 1)) * ld * (b / b_glob)
+    valid = idx > 0
+    l_flow = torch.zeros(())
+    if bool(valid.any()):
+        m = masks[idx][valid]
+        l_flow = (O.warp_flow(pre, flows[idx])[valid] * m - images[valid] * m).abs().sum() / (nvalid_glob * 3 * h * w)
+    return (1 - lf) * l_photo + lf * l_flow + O.tv_loss(images, ltv) * (b / b_glob)
+
+
+def _partial_stage1(O, expo, edited, slots, b_glob, nvalid_glob, flows, masks, ld=0.2, lf=0.8):
+    idx = torch.tensor(slots, dtype=torch.int64)
+    _, _, h, w = edited.shape
+    cat_idx = torch.cat([idx, (idx - 1).clamp(min=0)])
+    cat = O.apply_exposure(edited[cat_idx], expo, cat_idx)
+    images, pre = cat[:len(idx)], cat[len(idx):]
+    b = len(idx)
+    tgt = edited[idx]
+    l_photo = ((images - tgt).abs().sum() / (b_glob * 3 * h * w)) * (1 - ld) + (1.0 - O.relaxed_ms_ssim(images, tgt, 1.0, 1)) * ld * (b / b_glob)
+    valid = idx > 0
+    l_flow = torch.zeros(())
+    if bool(valid.any()):
+        m = masks[idx][valid]
+        l_flow = (O.warp_flow(pre, flows[idx])[valid] * m - images[valid] * m).abs().sum() / (nvalid_glob * 3 * h * w)
+    return (1 - lf) * l_photo + lf * l_flow
+
+
+def _adam(p, g, m, v, lr, eps, t):
+    m.mul_(0.9).add_(g, alpha=0.1)
+    v.mul_(0.999).addcmul_(g, g, value=0.001)
+    p.addcdiv_(m, (v.sqrt() / (1 - 0.999 ** t) ** 0.5).add_(eps), value=-lr / (1 - 0.9 ** t))
+    g.zero_()
+
+
+def _stage_inputs():
+    import synth
+    d = synth.video_clip(5, 176, 192, seed=11)
+    inv, k = synth.track_ids(5, 176, 192, seed=3)
+    sched = [[1, 3, 0, 4], [2, -1, -1, -1], [4, 2, 3, -1]]        # full batch, a batch smaller than the world, a short batch
+    return d, inv, k, sched
+
+
+def _stage_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import path2 as O
+    from tc_light_amd.hostlogic import expon_lr
+    from tc_light_amd.parallel import Dist, distributed_adam_loop
+    d = Dist(rank, world)
+    data, inv, k, sched = _stage_inputs()
+    ed, fl, mk = data["edited"], data["past_flows"], data["masks"]
+    n, _, h, w = ed.shape
+    # ---- stage 1: replicated Adam on the all-reduced [N,3,4] gradient
+    expo = torch.eye(3, 4)[None].repeat(n, 1, 1).contiguous()
+
+    def grad1(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
+        e = p_full.view(n, 3, 4).clone().requires_grad_(True)
+        loss = _partial_stage1(O, e, ed, slots, b_glob, nvalid, fl, mk)
+        (g,) = torch.autograd.grad(loss, e)
+        g_full.add_(g.reshape(-1)); loss_out.copy_(loss.detach().reshape(1))
+
+    def adam1(it, p, g, m, v):
+        _adam(p, g, m, v, expon_lr(it + 1, 0.01, 0.001, 3), 1e-8, it + 1)
+    l1 = distributed_adam_loop(d, sched, expo.view(-1), torch.zeros(n * 12), grad1, adam1, shard_state=False)
+    # ---- stage 2: sharded Adam state, reduce_scatter(grad) + all_gather(rows)
+    pix = ed.permute(0, 2, 3, 1).reshape(n * h * w, 3)
+    feats0 = O.rgb2sh(O.scatter_mean(pix, inv))
+    npad = -(-3 * k // world) * world
+    flat = torch.zeros(npad); flat[:3 * k] = feats0.reshape(-1)
+    inv_nhw = inv.reshape(n, h, w).long()
+    lr = 0.05 * 4 / n
+
+    def grad2(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
+        f = p_full[:3 * k].view(k, 3).clone().requires_grad_(True)
+        loss = _partial_stage2(O, f, inv_nhw, slots, b_glob, nvalid, ed, fl, mk)
+        (g,) = torch.autograd.grad(loss, f)
+        g_full[:3 * k].add_(g.reshape(-1)); loss_out.copy_(loss.detach().reshape(1))
+
+    def adam2(it, p, g, m, v):
+        _adam(p, g, m, v, lr, 1e-15, it + 1)
+    l2 = distributed_adam_loop(d, sched, flat, torch.zeros(npad), grad2, adam2, shard_state=True)
+    if rank == 0:
+        ret.put((expo, l1, flat[:3 * k].view(k, 3).clone(), l2))
+    dist.destroy_process_group()
+
+
+def test_global_stage1_stage2_world2_equals_single_process():
+    from oracle import path2 as O
+    ctx = mp.get_context("spawn")
+    ret = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    expo, l1, feats, l2 = ret.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    data, inv, k, sched = _stage_inputs()
+    ed, fl, mk = data["edited"], data["past_flows"], data["masks"]
+    batches = [torch.tensor([f for f in row if f >= 0], dtype=torch.int64) for row in sched]
+    # single-process oracle loops (epochs = iterations here: one batch per "epoch" keeps the lr law's step = it + 1)
+    _, expo_ref, l1_ref = O.exposure_align(ed, fl, mk, batches, epochs=3, batch_size=ed.shape[0], lr_init=0.01, lr_final=0.001)
+    assert torch.allclose(l1, torch.tensor(l1_ref), rtol=2e-5, atol=1e-7), (l1, l1_ref)
+    # frame 0 of a stage-1 run from exposure = I sees pure rounding-noise gradients that Adam(eps 1e-8) amplifies (DESIGN conditioning note):
+    # compare the frames that receive a real gradient tightly, frame 0 only through the losses above
+    assert (expo[1:] - expo_ref[1:]).abs().max() < 2e-5
+    _, feats_ref, l2_ref = O.unique_tensor_optimization(ed, inv, fl, mk, batches, 4)
+    assert torch.allclose(l2, torch.tensor(l2_ref), rtol=2e-5, atol=1e-7), (l2, l2_ref)
+    diff = (feats - feats_ref).abs()
+    assert (diff > 1e-4).float().mean() < 2e-3 and diff.median() < 1e-6       # Adam(eps 1e-15) on cancelling gradients: a few noise rows

@@ -45,18 +45,36 @@ def test_rmbg_estimate_alpha_vs_oracle(eng):
     assert got.min().item() >= 0.0 and got.max().item() <= 1.0
 
 
-def test_prepare_data_background_blend(eng):
-    """generate.py:147-167 through Generator.prepare_data: alpha*fg + (1-alpha)*bg with the engine's matte (UNet / VAE not needed here)."""
+def test_prepare_data_background_blend_and_noise_modes(eng):
+    """generate.py:138-204 through Generator.prepare_data (UNet / VAE not needed here): the blend `alpha*fg + (1-alpha)*bg` against the
+    ORACLE's matte (oracle/rmbg.py::estimate_alpha, pinned to the reference module) on a non-square 720x960-shaped (scaled) frame so the
+    transposed `resized_size` of generate.py:152-153 matters; noise_mode "same" = one [1,4,h,w] draw repeated, "vanilla" = N independent
+    draws (:174-188), anything else raises."""
     from types import SimpleNamespace
+    from oracle import rmbg as OR
     from tc_light_amd.generate import Generator
     e, sd, _ = eng
     dev = torch.device("cuda")
-    stub = SimpleNamespace(dev=dev, tome=SimpleNamespace(args={}))
+    stub = SimpleNamespace(dev=dev, tome=SimpleNamespace(args=dict(target_stride=4)))
     gen = Generator(stub, None, dict(noise_mode="same"), rmbg=e)
     g = np.random.default_rng(4)
-    fg = torch.from_numpy(g.random((2, 3, 128, 192)).astype(np.float32)).to(dev)
-    bg = torch.from_numpy(g.random((1, 3, 128, 192)).astype(np.float32)).to(dev)
-    gen.prepare_data(fg, background=bg)
-    alpha = e.estimate_alpha(fg)
-    assert torch.allclose(gen.frames, alpha * fg + (1 - alpha) * bg)
-    assert gen.init_noise.shape == (2, 4, 16, 24)
+    fg = torch.from_numpy(g.random((3, 3, 144, 192)).astype(np.float32))
+    bg = torch.from_numpy(g.random((1, 3, 144, 192)).astype(np.float32))
+    gen.prepare_data(fg.to(dev), background=bg.to(dev))
+    with torch.no_grad():
+        alpha = OR.estimate_alpha(sd, fg)
+    want = alpha * fg + (1 - alpha) * bg
+    err = (gen.frames.cpu() - want).abs()
+    assert err.max().item() < 1e-3 and err.mean().item() < 2e-5, (err.max().item(), err.mean().item())
+    assert gen.init_noise.shape == (3, 4, 18, 24)
+    assert torch.equal(gen.init_noise[0], gen.init_noise[1]) and torch.equal(gen.init_noise[0], gen.init_noise[2])     # "same"
+    first = gen.init_noise[0].clone()
+    gen2 = Generator(stub, None, dict(noise_mode="vanilla"), rmbg=e)
+    gen2.prepare_data(fg.to(dev))
+    assert torch.equal(gen2.frames, fg.to(dev))                     # no background -> frames untouched
+    assert not torch.equal(gen2.init_noise[0], gen2.init_noise[1])  # independent per frame
+    assert abs(gen2.init_noise.float().std().item() - 1.0) < 0.05 and abs(first.float().std().item() - 1.0) < 0.1
+    with pytest.raises(NotImplementedError):
+        Generator(stub, None, dict(noise_mode="other"), rmbg=e).prepare_data(fg.to(dev))
+    with pytest.raises(RuntimeError):
+        Generator(stub, None, dict(noise_mode="same")).prepare_data(fg.to(dev), background=bg.to(dev))   # no RMBG engine

@@ -32,6 +32,7 @@ generation:
   alpha_t: 0.01
   frame_range: [0, 4, 1]
 post_opt: {{epochs_exposure: 1, epochs: 1, batch_size: 4}}
+models: {{allow_random: true}}
 """)
     cwd = os.getcwd()
     os.chdir(tmp_path)
@@ -47,7 +48,15 @@ post_opt: {{epochs_exposure: 1, epochs: 1, batch_size: 4}}
         assert len(outs) == 1
         out = np.load(outs[0])
         assert out.shape == (4, 192, 256, 3) and out.dtype == np.uint8
-        assert os.path.exists(os.path.join(os.path.dirname(outs[0]), "config.yaml"))
+        odir = os.path.dirname(outs[0])
+        assert os.path.exists(os.path.join(odir, "config.yaml"))
+        assert any(f.startswith("output_gt") for f in os.listdir(odir))                       # generate.py:619-625
+        assert sorted(os.listdir(os.path.join(odir, "frames"))) == [f"{i:04d}.png" for i in range(4)]     # save_frame: true (default yaml)
+        assert os.path.exists(os.path.join(odir, "loss_exposure.npy")) and os.path.exists(os.path.join(odir, "loss_unique_tensor.npy"))
+        bad = tmp_path / "strict.yaml"                                                        # without allow_random missing weights are an error
+        bad.write_text(cfg.read_text().replace("allow_random: true", "allow_random: false"))
+        with pytest.raises(FileNotFoundError):
+            run.main(["--config", str(bad)])
         run.main(["--config", str(cfg)])               # second run: flows come from the cache
     finally:
         os.chdir(cwd)

@@ -143,7 +143,7 @@ class VidToMe:
         if bank is None:                                                        # patch.py:81-82: the first chunk seeds the bank
             self.banks[name] = local if F > 1 else local.clone()
             if self.trace is not None:
-                self.trace.append(dict(name=name, unm=unm1, gather=mrg1, T=TL))
+                self.trace.append(dict(name=name, F=F, unm=unm1, gather=mrg1, mrg1=mrg1, T=TL))
             return local, unm1, TL
         Tb = bank.shape[1]
         if self.coin > a["global_rand"]:                                        # patch.py:61-65: local tokens are src
@@ -166,5 +166,5 @@ class VidToMe:
         L.tcl_gather_rows_f16(cat, T * C, 0, 0, bmap, nb_, TL * C, 2, TL, C, stream())
         self.banks[name] = nb_
         if self.trace is not None:
-            self.trace.append(dict(name=name, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL))
+            self.trace.append(dict(name=name, F=F, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL, bmap=bmap))
         return merged, unm, Tm

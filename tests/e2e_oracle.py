@@ -1,0 +1,184 @@
+"""Test harness: the whole TC-Light path on the CPU oracle (oracle/sd15 + vidtome + pipeline + scheduler + path2), composed the way
+the reference's Generator.__call__ composes it (generate.py:560-611), next to instrumentation that records what the HIP engine drew /
+decided so both runs see identical seeds.  TEST INFRASTRUCTURE (imports oracle/): only tests use it.
+
+VidToMe's matching is discrete; two ways of running the oracle UNet with merging ON:
+  * InjectedToMe -- replays the engine's merge maps (recorded through VidToMe.trace): pure numeric parity of everything else;
+  * ComputedToMe -- the oracle decides itself (oracle/vidtome.py, f16-emulating score rule) from the same (randf, coin) draws.
+Both keep one global-token bank per block across the chunks of a step -- and across the xy -> yt passes of a step: the reference resets
+the banks only in post_iter (generate_utils.py:235-238).
+"""
+import math
+from collections import defaultdict, deque
+
+import numpy as np
+import torch
+
+from oracle import path2 as O2
+from oracle import pipeline as OP
+from oracle import sd15 as OS
+from oracle import vidtome as OV
+from oracle.scheduler import Scheduler as OSch
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+class Recorder:
+    """Wraps a Generator's scheduler / VidToMe to log the SDE noise, the latents entering each step, the fused noise prediction, the
+    (randf, coin) draws and the merge maps of one run."""
+
+    def __init__(self, gen):
+        self.gen, self.zs, self.seen, self.draws = gen, [], [], []
+        tome = gen.unet.tome
+        tome.trace = []
+        self._step, self._begin = gen.scheduler.step, tome.begin_step
+
+        def step(eps, t, x, noise=None, **kw):
+            self.zs.append(None if noise is None else noise.float().cpu())
+            self.seen.append((x.float().cpu(), eps.float().cpu()))
+            return self._step(eps, t, x, noise=noise, **kw)
+
+        def begin_step(Fs, size):
+            self._begin(Fs, size)
+            self.draws.extend((f, r, c) for f, r, c in tome._chunks)
+        gen.scheduler.step, tome.begin_step = step, begin_step
+
+    def finish(self):
+        tome = self.gen.unet.tome
+        tr, tome.trace = tome.trace, None
+        self.gen.scheduler.step, tome.begin_step = self._step, self._begin
+        cpu = lambda v: v.cpu().long() if isinstance(v, torch.Tensor) else v
+        self.traces = [{k: cpu(v) for k, v in d.items()} for d in tr]
+        return self
+
+
+def _merges(size, N, max_downsample=2):
+    return int(math.ceil(math.sqrt((size[0] * size[1]) // N))) <= max_downsample
+
+
+class InjectedToMe:
+    def __init__(self, traces):
+        self.q = defaultdict(deque)
+        for t in traces:
+            self.q[t["name"]].append(t)
+        self.banks = {}
+
+    def reset(self):
+        self.banks.clear()
+
+    def next_chunk(self):
+        pass
+
+    def hook(self, size):
+        def tome(p, n1):
+            B2, N, C = n1.shape
+            F = B2 // 2
+            if not _merges(size, N):
+                return n1, (lambda y: y)
+            tr = self.q[p].popleft()
+            assert tr["F"] == F, (p, tr["F"], F)
+            xj = n1.reshape(2, F * N, C)
+            local = xj[:, tr["mrg1"]] if tr.get("mrg1") is not None else xj
+            unm = tr["unm"] if tr["unm"] is not None else torch.arange(F * N)
+            un = lambda y: y[:, unm].reshape(B2, N, C)
+            if "mrg2" not in tr:
+                self.banks[p] = local.clone()
+                return local, un
+            bank = self.banks[p]
+            TL, Tb = tr["TL"], bank.shape[1]
+            assert TL == local.shape[1]
+            cat = torch.empty(2, TL + Tb, C)
+            cat[:, tr["loff"]:tr["loff"] + TL] = local
+            cat[:, tr["boff"]:tr["boff"] + Tb] = bank
+            self.banks[p] = cat[:, tr["bmap"]]                  # bank <- u(merged_tokens), local chunk (patch.py:80)
+            return cat[:, tr["mrg2"]], un
+        return tome
+
+    def exhausted(self):
+        return all(len(q) == 0 for q in self.q.values())
+
+
+class ComputedToMe:
+    def __init__(self, draws, local_ratio=0.6, global_ratio=0.5, global_rand=0.5, traces=None):
+        self.draws, self.banks = deque(draws), {}
+        self.lr, self.gr, self.grand = local_ratio, global_ratio, global_rand
+        self.q = defaultdict(deque)
+        for t in traces or []:
+            self.q[t["name"]].append(t)
+        self.agree = []
+        self.cur = None
+
+    def reset(self):
+        self.banks.clear()
+
+    def next_chunk(self):
+        self.cur = self.draws.popleft()
+
+    def hook(self, size):
+        def tome(p, n1):
+            B2, N, C = n1.shape
+            F = B2 // 2
+            if not _merges(size, N):
+                return n1, (lambda y: y)
+            f, randf, coin = self.cur
+            assert f == F
+            r = OV.compute_merge(n1, F, self.banks.get(p), randf, coin, self.lr, self.gr, self.grand, emulate_f16=True)
+            self.banks[p] = r["bank_new"]
+            if self.q[p]:
+                tr = self.q[p].popleft()
+                hu = tr["unm"] if tr["unm"] is not None else torch.arange(F * N)
+                self.agree.append((r["unm"] == hu).float().mean().item() if r["merged"].shape[1] == tr["T"] else 0.0)
+            return r["merged"], r["unmerge"]
+        return tome
+
+
+def oracle_denoise(sd_unet, x0, cc, text, text_t, cfg, tome, zs, xy_seed, yt_seed, on_step=None):
+    """Generator.ddim_sample (generate.py:208-239) on the oracle: x0, cc [N,4,h,w] f32; cfg: the Generator's config namespace."""
+    from tc_light_amd import hostlogic as HL            # the chunk draws: integer host logic pinned by tests/test_hostlogic_cpu.py
+    c = cfg
+    n, _, h, w = x0.shape
+    osch = OSch(c.n_timesteps)
+    alphas = OP.alpha_schedule(c.alpha_t, c.final_factor_t, c.n_timesteps)
+    xy_s = HL.ChunkSampler(xy_seed, c.chunk_size, c.merge_global, c.chunk_ord)
+    yt_s = HL.ChunkSampler(yt_seed, c.chunk_size, c.merge_global, c.chunk_ord)
+    x = x0.clone()
+
+    def pred(xin, txt, t, size):
+        tome.next_chunk()
+        return OP.cfg(OS.unet_forward(sd_unet, torch.cat([xin, xin]), t, txt, tome.hook(size)), c.guidance_scale)
+
+    for i, t in enumerate(osch.timesteps.tolist()):
+        noises = torch.zeros_like(x)
+        for ch in xy_s.get_chunks(n):
+            noises[ch] = pred(torch.cat([x[ch], cc[ch]], 1), text, float(t), (h, w))
+        if c.alpha_t > 0:
+            yt_chunks = [torch.as_tensor(ch) for ch in yt_s.get_chunks(w)]
+            noises = OP.temporal_denoise(x, cc, alphas[i], noises, c.win_size_t, yt_chunks,
+                                         lambda xt, ct, ch, sl: pred(torch.cat([xt, ct], 1), text_t, float(t), (xt.shape[2], h)))[1]
+        if on_step is not None:
+            on_step(i, x, noises)
+        z = zs[i] if zs[i] is not None else torch.zeros_like(x)
+        x = osch.step(noises, x, z)
+        tome.reset()                                       # post_iter
+    return x
+
+
+def oracle_post_opt(clean, flows, masks, inv, cfg, n):
+    """exposure_align + unique_tensor_optimization (generate.py:354-533) with the engine's mini-batch schedule."""
+    from tc_light_amd import post_opt
+    rng = np.random.default_rng(cfg.seed)
+    s1 = post_opt.make_schedule(n, cfg.batch_size, cfg.epochs_exposure, rng)
+    s2 = post_opt.make_schedule(n, cfg.batch_size, cfg.epochs, rng)
+    tob = lambda s: [torch.tensor([f for f in r if f >= 0], dtype=torch.int64) for r in s]
+    aligned, expo, l1 = O2.exposure_align(clean, flows, masks, tob(s1), cfg.epochs_exposure, cfg.batch_size, cfg.exposure_lr_init,
+                                          cfg.exposure_lr_final, cfg.lambda_dssim, cfg.lambda_flow)
+    out, feats, l2 = O2.unique_tensor_optimization(aligned, inv, flows, masks, tob(s2), cfg.batch_size, cfg.feature_lr, cfg.lambda_dssim,
+                                                   cfg.lambda_flow, cfg.lambda_tv)
+    return aligned, out, l1, l2
+
+
+def vae_batches(fn, sd, x, bs=2):
+    with torch.no_grad():
+        return torch.cat([fn(sd, x[i:i + bs]) for i in range(0, len(x), bs)])

@@ -1,0 +1,165 @@
+"""GPU: END-TO-END parity of the whole path -- Generator.__call__ (reference generate.py:560-611: VAE encode -> denoising loop with VidToMe
+ON through the default block-major `forward_many` schedule -> VAE decode -> stage 1 -> stage 2) against the same composition on the CPU
+oracle (tests/e2e_oracle.py) with identical seeds: same synthetic frames, seeded weights, initial noise, chunk draws, VidToMe draws, SDE
+noise and mini-batch schedules.
+
+test_config1_end_to_end  = BASELINE.json configs[0] IN FULL: 8 frames 512x512, 4 denoising steps, single axis (alpha_t = 0), VidToMe 0.6/0.5,
+                           stage 1 35 epochs + stage 2 70 epochs (TCL_E2E_EPOCHS="a,b" shortens the optimiser for quick local runs).
+test_multi_axis_bank_carry_over = a small multi-axis run with VidToMe ON: pins that the global-token banks the xy pass leaves behind are
+                           the ones the yt pass of the same step starts from (reset only in post_iter, generate_utils.py:235-238).
+
+Tolerances (north_star: 1e-3 rel-L2 on the output).  The engine computes in f16 with f32 accumulation, the oracle in f32; the UNet/VAE
+arithmetic of the oracle is parity-unpinned w.r.t. diffusers (oracle/sd15.py header).  With the engine's merge maps injected into the
+oracle the final frames must agree to 1e-3 rel-L2 (asserted); with the oracle's own matching the discrete decisions differ on near-tied
+f16 scores and the figure is printed and bounded loosely.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import e2e_oracle as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(vidtome_seed=12345):
+    from tc_light_amd import sd15
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vae import VAEEngine
+    from tc_light_amd.vidtome import VidToMe
+    sd_unet = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
+    sd_vae = sd15.random_state_dict(sd15.vae_param_shapes(), seed=2)
+    return sd_unet, sd_vae, UNetEngine(sd_unet, "cuda", VidToMe("cuda", seed=vidtome_seed)), VAEEngine(sd_vae, "cuda")
+
+
+def _text(seed, L):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy(g.standard_normal((2, L, 768)).astype(np.float32)).half()
+
+
+def test_config1_end_to_end():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd.generate import Generator
+    e1, e2 = (int(v) for v in os.environ.get("TCL_E2E_EPOCHS", "35,70").split(","))
+    n, H, W = 8, 512, 512
+    cfg = dict(n_timesteps=4, alpha_t=0.0, epochs_exposure=e1, epochs=e2, batch_size=16, seed=12345)
+    sd_unet, sd_vae, unet, vae = _engines()
+    d = synth.video_clip(n, H, W, seed=12345)
+    inv, k = synth.track_ids(n, H, W, seed=3)
+    conds, conds_t = _text(5, 154), _text(6, 77)
+    gen = Generator(unet, vae, cfg)
+    rec = E.Recorder(gen)
+    stages = {}
+    enc, dec = vae.encode_imgs_batch, vae.decode_latents_batch
+    vae.encode_imgs_batch = lambda x, bs: stages.setdefault("cc", enc(x, bs))
+    vae.decode_latents_batch = lambda z, bs: stages.setdefault("clean", dec(stages.setdefault("lat", z.clone()), bs))
+    t0 = time.time()
+    out, info = gen(d["frames"].cuda(), conds.cuda(), conds_t.cuda(), d["past_flows"].cuda(), d["masks"].cuda(), inv.cuda().int(), n_total=n, k=k)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    rec.finish()
+    vae.encode_imgs_batch, vae.decode_latents_batch = enc, dec
+    assert torch.isfinite(out).all() and len(rec.zs) == 4
+    n_merge_events = len(rec.traces)
+    assert n_merge_events == 10 * len(rec.draws) and len(rec.draws) >= 4 * 2           # 10 merging blocks x chunks x steps
+
+    # ------------------------------------------------------------------ the oracle, same seeds
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    t0 = time.time()
+    c = gen.cfg
+    cc = E.vae_batches(E.OS.vae_encode, sd_vae, d["frames"])
+    x0 = gen.init_noise.float().cpu()
+    tome_i = E.InjectedToMe(rec.traces)
+    with torch.no_grad():
+        lat_i = E.oracle_denoise(sd_unet, x0, cc, conds.float(), conds_t.float(), c, tome_i, rec.zs, c.seed, c.seed + 1)
+    assert tome_i.exhausted()
+    clean_i = E.vae_batches(E.OS.vae_decode, sd_vae, lat_i)
+    t_den = time.time() - t0
+    _, final_i, l1, l2 = E.oracle_post_opt(clean_i, d["past_flows"], d["masks"], inv, c, n)
+    t_all = time.time() - t0
+    r = dict(encode=E.rel(stages["cc"].cpu(), cc), latents=E.rel(stages["lat"].cpu(), lat_i), decoded=E.rel(stages["clean"].cpu(), clean_i),
+             final=E.rel(out.cpu(), final_i))
+    print(f"[e2e config 1, injected maps] HIP {t_hip:.1f} s (cold) vs oracle {t_all:.0f} s on {torch.get_num_threads()} threads (denoise+VAE {t_den:.0f} s); "
+          f"rel-L2: " + ", ".join(f"{k_} {v:.2e}" for k_, v in r.items()))
+    l1h, l2h = info["losses_exposure"].cpu().numpy(), info["losses_unique"].cpu().numpy()
+    print(f"[e2e config 1] stage-1 loss first/last HIP {l1h[0]:.5f}/{l1h[-1]:.5f} oracle {l1[0]:.5f}/{l1[-1]:.5f}; "
+          f"stage-2 HIP {l2h[0]:.5f}/{l2h[-1]:.5f} oracle {l2[0]:.5f}/{l2[-1]:.5f}")
+    assert r["encode"] < 2e-3 and r["latents"] < 5e-3 and r["decoded"] < 1e-3
+    assert r["final"] < 1e-3, r                                   # north_star: output within 1e-3 rel-L2
+    np.testing.assert_allclose(l1h, np.asarray(l1), rtol=2e-2)
+    np.testing.assert_allclose(l2h, np.asarray(l2), rtol=2e-2)
+
+    # ------------------------------------------------------------------ the oracle deciding its own matches
+    if os.environ.get("TCL_E2E_COMPUTED", "1") != "0":
+        tome_c = E.ComputedToMe(rec.draws, traces=rec.traces)
+        with torch.no_grad():
+            lat_c = E.oracle_denoise(sd_unet, x0, cc, conds.float(), conds_t.float(), c, tome_c, rec.zs, c.seed, c.seed + 1)
+        clean_c = E.vae_batches(E.OS.vae_decode, sd_vae, lat_c)
+        rc = dict(latents=E.rel(stages["lat"].cpu(), lat_c), decoded=E.rel(stages["clean"].cpu(), clean_c))
+        ag = np.asarray(tome_c.agree)
+        print(f"[e2e config 1, computed maps] unmerge-map agreement mean {ag.mean():.3f} min {ag.min():.3f} over {len(ag)} merges; rel-L2: "
+              + ", ".join(f"{k_} {v:.2e}" for k_, v in rc.items()))
+        assert rc["decoded"] < 5e-2 and ag.mean() > 0.6
+
+
+def test_multi_axis_bank_carry_over():
+    """6 frames, 16x16 latents, 2 steps, alpha_t > 0, window 4 (two overlapping yt windows), VidToMe ON: per step the oracle is fed the
+    latents the engine had and must reproduce the fused noise it handed to the scheduler, with the engine's maps injected.  The yt pass of
+    a step replays maps whose `mrg2`/`bmap` refer to banks the xy pass left: if the engine had reset (or failed to carry) the banks between
+    the passes the first yt chunk would be a seeding event without `mrg2` and the assertion on the trace structure below fails."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd.generate import Generator
+    sd_unet, _, unet, _ = _engines(vidtome_seed=5)
+    n, hh, ww = 6, 16, 16
+    cfg = dict(n_timesteps=2, alpha_t=0.3, final_factor_t=0.5, win_size_t=4, chunk_size=4, guidance_scale=2.0, seed=77, noise_mode="vanilla")
+    g = Generator(unet, None, cfg)
+    g.prepare_data(torch.zeros(n, 3, 8 * hh, 8 * ww, device="cuda"))
+    gen = torch.Generator().manual_seed(3)
+    conds, conds_t = torch.randn(2, 154, 768, generator=gen).half(), torch.randn(2, 77, 768, generator=gen).half()
+    cc = torch.randn(n, 4, hh, ww, generator=gen).half()
+    x0 = g.init_noise.clone()
+    rec = E.Recorder(g)
+    x_hip = g.ddim_sample(x0.clone(), conds.cuda(), conds_t.cuda(), cc.cuda()).float().cpu()
+    torch.cuda.synchronize()
+    rec.finish()
+    # trace structure: per merging block and step, exactly ONE seeding event (the first xy chunk); every yt chunk merges against a bank
+    per_block = {}
+    for t in rec.traces:
+        per_block.setdefault(t["name"], []).append("mrg2" in t)
+    assert len(per_block) == 10
+    for name, ev in per_block.items():
+        assert ev.count(False) == 2, (name, ev)                 # 2 steps -> 2 seeds; all later chunks (xy and yt) use the carried bank
+    tome = E.InjectedToMe(rec.traces)
+    fused = []
+    with torch.no_grad():
+        # replay step by step from the engine's own latents (per-step parity, no error carry-over)
+        from oracle.scheduler import Scheduler as OSch
+        from tc_light_amd import hostlogic as HL
+        c = g.cfg
+        osch = OSch(c.n_timesteps)
+        alphas = E.OP.alpha_schedule(c.alpha_t, c.final_factor_t, c.n_timesteps)
+        xy_s, yt_s = HL.ChunkSampler(c.seed, c.chunk_size, c.merge_global, c.chunk_ord), HL.ChunkSampler(c.seed + 1, c.chunk_size, c.merge_global, c.chunk_ord)
+        ccf, text, text_t = cc.float(), conds.float(), conds_t.float()
+
+        def pred(xin, txt, t, size):
+            return E.OP.cfg(E.OS.unet_forward(sd_unet, torch.cat([xin, xin]), t, txt, tome.hook(size)), c.guidance_scale)
+        for i, t in enumerate(osch.timesteps.tolist()):
+            x = rec.seen[i][0]
+            noises = torch.zeros_like(x)
+            for ch in xy_s.get_chunks(n):
+                noises[ch] = pred(torch.cat([x[ch], ccf[ch]], 1), text, float(t), (hh, ww))
+            fz = E.OP.temporal_denoise(x, ccf, alphas[i], noises, c.win_size_t, [torch.as_tensor(ch) for ch in yt_s.get_chunks(ww)],
+                                       lambda xt, ct, ch, sl: pred(torch.cat([xt, ct], 1), text_t, float(t), (xt.shape[2], hh)))[1]
+            tome.reset()
+            r = E.rel(rec.seen[i][1], fz)
+            print(f"[multi-axis, VidToMe on, injected] step {i}: fused eps rel-L2 = {r:.3e}")
+            fused.append(r)
+    assert tome.exhausted()
+    assert max(fused) < 1e-2, fused
+    assert torch.isfinite(x_hip).all()

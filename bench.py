@@ -2,12 +2,17 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one full pass of the hot path over the workload: VAE encode -> 20-step multi-axis denoise (xy + yt planes,
-VidToMe) -> VAE decode -> stage 1 (35 epochs) -> stage 2 (70 epochs), i.e. the region the reference times
-(generate.py:578-611) minus optical-flow estimation (precomputed input).  Workload at N=1 = BASELINE.json
-configs[1]: 30 frames 960x720, 20 steps, --multi_axis; N GPUs relight 30*N frames (weak scaling, frames sharded).
-Weights are seeded random tensors of the SD-1.5 / AutoencoderKL architecture, inputs synthetic (no network); all inputs are
-resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+Workload = the configuration BASELINE.json's metric is quoted on: 300 frames 1280x720, 20 denoising steps, --multi_axis (alpha_t 0.01),
+VidToMe 0.6/0.5, stage 1 35 epochs + stage 2 70 epochs -- the region the reference times (generate.py:578-611) minus optical-flow
+estimation (precomputed input).  It fits ONE MI355X (about 42 GB of the 288 GB), so N=1 runs exactly it; N GPUs relight the
+SAME 300-frame clip with the frames sharded (strong scaling; yt-plane all-gather / all-reduce per step, one global stage-1/2 parameter set).
+
+A "step" is one denoising step of the end-to-end pass: the timed region is ONE pass of K denoising steps (K = 20 is the BASELINE
+configuration; VAE encode / decode and both optimiser stages are inside the timed region and amortised into ms_per_step) and
+`value` = frames / wall(pass).  W warm-up steps = an untimed truncated pass (W denoising steps, one epoch of each stage) on the same
+inputs: it warms the allocator pools and, when the committed GEMM tile table lacks a shape, the autotuner.  K that is a multiple of 20
+runs K/20 full passes.  Weights are seeded random tensors of the SD-1.5 / AutoencoderKL architecture, inputs synthetic (no network); all
+inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -24,22 +29,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16 (spec; 2.49 PF measured)
+BASE_STEPS = 20                       # BASELINE.json: 20 denoising steps
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=30, help="frames per GPU")
+    ap.add_argument("--steps", type=int, default=BASE_STEPS, help="denoising steps of the timed pass (20 = BASELINE; multiples of 20 = several passes)")
+    ap.add_argument("--warmup", type=int, default=5, help="denoising steps of the untimed warm-up pass")
+    ap.add_argument("--frames", type=int, default=300, help="frames of the clip (total, sharded over the GPUs)")
     ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--width", type=int, default=960)
-    ap.add_argument("--n_timesteps", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--epochs_exposure", type=int, default=35)
     ap.add_argument("--epochs", type=int, default=70)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_extras", action="store_true", help="skip the flow-estimation / matting timings reported beside the metric")
+    ap.add_argument("--no_extras", action="store_true", help="skip the figures reported beside the metric (configs[1] pass, flow estimation / matting)")
+    ap.add_argument("--exclusive", action="store_true", help="one extra untimed pass with the matching chain on the main stream (flash kernel alone on the GPU)")
     ap.add_argument("--no_multi_axis", action="store_true")
+    ap.add_argument("--save_gemm_table", type=str, default=None, help="write the GEMM tile table after the run (to refresh tc_light_amd/gemm_tune_gfx950.txt)")
     return ap.parse_args()
 
 
@@ -73,39 +80,57 @@ def producer_timings(frames, dev):
             "note": "MemFlowNet (15 iterations) and BriaRMBG engines on 8 frames of the workload, seeded random weights; not part of value"}
 
 
-def cpu_baseline(sd_unet, H, W, n_frames, n_steps, multi_axis, flops_path1, cfg):
-    """The oracle ("port") timed on this host's cores on a bounded sample, extrapolated by algorithmic work:
-    path 1 by FLOP rate of one full-resolution single-frame UNet evaluation; path 2 by measured time per iteration."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd_unet, H, W, n_frames, flops_path1, cfg):
+    """The oracle ("port": oracle/sd15.py + oracle/path2.py, the CPU restatement of the reference's PyTorch path) timed on this host's cores
+    on a bounded sample of THIS workload (cut to fit the ~10-30 s the harness allows): at the FULL latent resolution one
+    xy-plane UNet call on one frame (batch 2 = uncond + cond, L = 154) and one yt-plane call on one latent column of a 64-frame window
+    (L = 77), and at the FULL image resolution one iteration each of stage 1 and stage 2 on a 2-frame mini-batch.  Extrapolated by work:
+    path 1 = the pass's algorithmic UNet FLOPs / the measured CPU FLOP rate; path 2 = iterations x measured seconds per iteration scaled
+    from 2 to `batch_size` frames.  VAE time is left out (in the CPU's favour)."""
     from oracle import path2 as O2
     from oracle import sd15 as OS
     import synth
-    cores = min(os.cpu_count(), 64)             # torch CPU kernels stop scaling (and oversubscribe) beyond this on the GPU hosts
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 64)             # torch CPU kernels stop scaling (and oversubscribe) beyond this on the GPU hosts
     torch.set_num_threads(cores)
-    # bounded sample (~10-30 s): the UNet on ONE frame at half the latent resolution, stage 2 on 2 frames at half resolution;
-    # scaled to the workload by algorithmic FLOPs (path 1) and by pixels x iterations (path 2).
-    h, w = H // 16, W // 16
+    h, w = H // 8, W // 8
     g = np.random.default_rng(0)
-    x = torch.from_numpy(g.standard_normal((2, 8, h, w)).astype(np.float32))
-    text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32))
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        OS.unet_forward(sd_unet, x, 801.0, text, None)
-    t_unet = time.perf_counter() - t0
-    fl = unet_flops_unmerged(2, h, w, 77)      # same accounting as UNetEngine._fl (B=2, F=1, no merging)
-    cpu_rate = fl / t_unet
-    H2, W2 = max(H // 2, 176), max(W // 2, 176)
-    d = synth.video_clip(3, H2, W2, seed=1)
-    inv, _ = synth.track_ids(3, H2, W2, seed=3)
+    meas = []
+    for (ph, pw, L) in ((h, w, 154), (min(64, n_frames), h, 77)):
+        x = torch.from_numpy(g.standard_normal((2, 8, ph, pw)).astype(np.float32))
+        text = torch.from_numpy(g.standard_normal((2, L, 768)).astype(np.float32))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            OS.unet_forward(sd_unet, x, 801.0, text, None)
+        meas.append((unet_flops_unmerged(2, ph, pw, L), time.perf_counter() - t0))
+    cpu_rate = sum(f for f, _ in meas) / sum(t for _, t in meas)
+    d = synth.video_clip(3, H, W, seed=1)
+    inv, _ = synth.track_ids(3, H, W, seed=3)
     bts = [torch.tensor([1, 2])]
     t0 = time.perf_counter()
+    O2.exposure_align(d["edited"], d["past_flows"], d["masks"], bts, 1, 2)
+    t_it1 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]
+    t0 = time.perf_counter()
     O2.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, 2)
-    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"] * (H * W) / (H2 * W2)     # per full-size 16-frame iteration
-    iters = (cfg["epochs_exposure"] + cfg["epochs"]) * -(-n_frames // cfg["batch_size"])
-    total = flops_path1 / cpu_rate + iters * t_it2
-    return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle UNet forward on 1 frame at latent {w}x{h} (batch 2, {fl / 1e12:.2f} TFLOP in {t_unet:.1f} s = {cpu_rate / 1e12:.3f} TFLOP/s) "
-                       f"+ 1 oracle stage-2 iteration on 2 frames {W2}x{H2} ({t_it2:.1f} s per full-size 16-frame iteration); extrapolated as "
-                       f"path-1 algorithmic FLOPs ({flops_path1 / 1e15:.2f} PFLOP) / CPU rate + {iters} optimiser iterations")
+    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]
+    per_epoch = -(-n_frames // cfg["batch_size"])
+    total = flops_path1 / cpu_rate + per_epoch * (cfg["epochs_exposure"] * t_it1 + cfg["epochs"] * t_it2)
+    return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port", host_cpu=_cpu_model(), host_logical_cpus=ncpu,
+                sample=f"oracle UNet forward at full latent resolution: xy plane {w}x{h} on 1 frame ({meas[0][0] / 1e12:.2f} TFLOP in {meas[0][1]:.1f} s) + yt "
+                       f"plane {h}x{min(64, n_frames)} on 1 column ({meas[1][0] / 1e12:.2f} TFLOP in {meas[1][1]:.1f} s) = {cpu_rate / 1e12:.3f} TFLOP/s on {cores} "
+                       f"threads; oracle stage-1 / stage-2 iteration on a 2-frame batch at {W}x{H} ({t_it1:.1f} / {t_it2:.1f} s per {cfg['batch_size']}-frame "
+                       f"iteration); extrapolated: {flops_path1 / 1e15:.2f} PFLOP of UNet work / CPU rate + {per_epoch * cfg['epochs_exposure']} + "
+                       f"{per_epoch * cfg['epochs']} optimiser iterations (VAE left out)")
 
 
 def unet_flops_unmerged(B, h, w, L):
@@ -147,15 +172,16 @@ def unet_flops_unmerged(B, h, w, L):
 
 def measured_traffic():
     """HBM-side bytes per k_flash<40,...> launch from the committed PMC passes (tools/collect_profiles.sh -> profiles/*_flash40_traffic.json).
-    PMC counters cannot be read from inside the timed process, so the newest committed measurement of this same command is reported."""
+    PMC counters cannot be read from inside the timed process, so the newest committed measurement of this same command is reported
+    together with the file it came from (it goes stale when attn.hip changes: the file name carries the round)."""
     import glob
-    fs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_flash40_traffic.json")))
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flash40_traffic.json")))
     if not fs:
-        return None
+        return None, None
     try:
-        return json.load(open(fs[-1]))["traffic_bytes_per_launch"]
+        return json.load(open(fs[-1]))["traffic_bytes_per_launch"], os.path.basename(fs[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -192,26 +218,30 @@ def main():
     d = Dist(rank, world)
     d.barrier()
 
-    n_total = a.frames * world
-    H, W = a.height, a.width
-    cfg = dict(n_timesteps=a.n_timesteps, alpha_t=0.0 if a.no_multi_axis else 0.01, final_factor_t=0.01, epochs_exposure=a.epochs_exposure,
-               epochs=a.epochs, batch_size=16, seed=12345)
+    n_total, H, W = a.frames, a.height, a.width
+    passes = a.steps // BASE_STEPS if (a.steps % BASE_STEPS == 0 and a.steps > 0) else 1
+    n_steps = BASE_STEPS if a.steps % BASE_STEPS == 0 else a.steps
+    base = dict(alpha_t=0.0 if a.no_multi_axis else 0.01, final_factor_t=0.01, batch_size=16, seed=12345)
+    cfg = dict(base, n_timesteps=n_steps, epochs_exposure=a.epochs_exposure, epochs=a.epochs)
     sd_unet = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
     sd_vae = sd15.random_state_dict(sd15.vae_param_shapes(), seed=2)
     unet = UNetEngine(sd_unet, dev, VidToMe(dev, seed=12345))
     vae = VAEEngine(sd_vae, dev)
+    table_entries = int(lib().tcl_gemm_tune_size())
     gen = Generator(unet, vae, cfg, dist=d)
     lo, hi = d.range(n_total)
+    t_setup = time.perf_counter()
     frames, flows, masks, inv, K = synth_inputs(n_total, H, W, lo, hi, dev)
+    t_setup = time.perf_counter() - t_setup
     g = np.random.default_rng(5)
     conds = torch.from_numpy(g.standard_normal((2, 154, 768)).astype(np.float32)).to(dev).half()     # 2 x 77-token chunks (A4)
     conds_t = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32)).to(dev).half()
 
-    def one_pass(profile=False):
+    def one_pass(generator, profile=False):
         if profile:
             lib().tcl_flash_profile_begin(40)
             unet.flops, unet.count_flops = 0.0, True
-        out, info = gen(frames, conds, conds_t, flows, masks, inv, n_total=n_total, k=K)
+        out, info = generator(frames, conds, conds_t, flows, masks, inv, n_total=n_total, k=K)
         prof = None
         if profile:
             ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
@@ -220,26 +250,27 @@ def main():
             unet.count_flops = False
         return out, info, prof
 
-    for _ in range(a.warmup):
-        one_pass()
+    if a.warmup > 0:       # untimed: W denoising steps + one epoch of each optimiser stage on the same inputs
+        one_pass(Generator(unet, vae, dict(base, n_timesteps=a.warmup, epochs_exposure=1, epochs=1), dist=d))
     d.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     info = prof = None
-    for s in range(a.steps):
-        out, info, p = one_pass(profile=(s == 0))
+    for s in range(passes):
+        out, info, p = one_pass(gen, profile=(s == 0))
         prof = prof or p
     d.barrier(); torch.cuda.synchronize()
     dt = d.max_float(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all(), "non-finite output"
+    if a.save_gemm_table and rank == 0:
+        lib().tcl_gemm_tune_save(a.save_gemm_table)
 
     # In the timed region the VidToMe matching chain runs on a second stream beside the attention kernels, so the launch
-    # durations above are those of a kernel SHARING the GPU.  One extra untimed pass with the chain back on the main stream gives the
-    # kernel's own rate; both are reported, `achieved` / `frac` stay the timed-region figures the rocprof summary agrees with.
+    # durations above are those of a kernel SHARING the GPU.  --exclusive: one extra untimed pass with the chain back on the main stream.
     prof_ex = None
-    if world == 1 and not a.no_extras:
+    if world == 1 and a.exclusive:
         os.environ["TCL_TOME_STREAM"] = "0"
         try:
-            _, _, prof_ex = one_pass(profile=True)
+            _, _, prof_ex = one_pass(gen, profile=True)
         finally:
             del os.environ["TCL_TOME_STREAM"]
         torch.cuda.synchronize()
@@ -247,36 +278,58 @@ def main():
     if rank == 0:
         ms, fl, cnt = prof
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        is_base = (n_total, H, W, n_steps, a.epochs_exposure, a.epochs, a.no_multi_axis) == (300, 720, 1280, BASE_STEPS, 35, 70, False)
+        traffic, traffic_src = measured_traffic()
         res = {
-            "metric": "relit frames/sec end-to-end (denoise+2-stage opt)", "value": n_total * a.steps / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{a.frames} frames/GPU {W}x{H}, {a.n_timesteps} denoise steps, "
+            "metric": "relit frames/sec end-to-end (denoise+2-stage opt)", "value": n_total * passes / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / (passes * n_steps) * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{n_total} frames {W}x{H}, {n_steps} denoise steps, "
                                    f"{'multi_axis (alpha_t=0.01)' if not a.no_multi_axis else 'single axis'}, VidToMe 0.6/0.5, stage-1 "
                                    f"{a.epochs_exposure} + stage-2 {a.epochs} epochs"
-                                   + (" (BASELINE.json configs[1])" if (a.frames, H, W, a.n_timesteps, a.epochs_exposure, a.epochs, a.no_multi_axis)
-                                      == (30, 720, 960, 20, 35, 70, False) else " (NOT the BASELINE workload: non-default flags)"),
-                       "frames_total": n_total, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
-                       "parallelism": f"frames sharded x{world}" if world > 1 else "single GPU"},
+                                   + (" (BASELINE.json metric configuration = configs[2]'s clip; fits one MI355X)" if is_base
+                                      else " (NOT the BASELINE workload: non-default flags)"),
+                       "step": "one denoising step of the end-to-end pass; the timed region is the whole pass (VAE encode/decode and both optimiser stages included)",
+                       "frames_total": n_total, "passes_timed": passes, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
+                       "parallelism": (f"frames sharded x{world} (38/37 per rank at 300), yt-plane all-gather + all-reduce per step, global stage-1/2 "
+                                       f"(gradient all-reduce / reduce-scatter)") if world > 1 else "single GPU",
+                       "gemm_tile_table_entries_loaded": table_entries},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
-            "roofline": {"bound": "mfma", "kernel": "k_flash<40,48,64,QB,NSTG,TPB> (head_dim 40 attention, self + text; 2 query blocks per wave, 4-slot ring, 2 tiles per barrier on long sequences, else 1 block, 3 slots)", "achieved": ach,
-                         "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
-                         "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": measured_traffic(),
-                         "unet_algorithmic_tflop_per_pass": unet.flops / 1e12},
+            "pass_seconds": dt / passes, "input_synthesis_seconds": round(t_setup, 1),
+            "max_memory_allocated_MiB": round(info["max_memory_allocated"]),
+            "roofline": {"bound": "mfma", "kernel": "k_flash<40,...> (head_dim 40 attention: self-attention over VidToMe-merged tokens + text cross-attention)",
+                         "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": unet.flops / 1e12,
+                         "how": "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"},
         }
         if prof_ex and prof_ex[0] > 0:
             ax = prof_ex[1] / (prof_ex[0] * 1e-3) / 1e12
             res["roofline"]["exclusive"] = {"achieved": ax, "frac": ax / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": prof_ex[0] / max(prof_ex[2], 1),
-                                            "how": "same launches in one extra untimed pass with the matching chain on the main stream "
-                                                   "(TCL_TOME_STREAM=0): the kernel alone on the GPU; profiles/*_exclusive* is the rocprof view"}
+                                            "how": "same launches in one extra untimed pass with the matching chain on the main stream (TCL_TOME_STREAM=0)"}
+        flops_pass = unet.flops
         if world == 1 and not a.no_extras:
+            del out
             try:                                               # the SURVEY 8(f) rows, measured beside the metric (never part of `value`)
                 res["producers"] = producer_timings(frames, dev)
             except Exception as e:
                 res["producers"] = {"error": repr(e)}
+            try:                                               # BASELINE.json configs[1] (round 1's bench workload), kept as an extra key
+                del frames, flows, masks, inv
+                torch.cuda.empty_cache()
+                f2, fl2, m2, i2, k2 = synth_inputs(30, 720, 960, 0, 30, dev)
+                g2 = Generator(unet, vae, dict(base, n_timesteps=BASE_STEPS, epochs_exposure=35, epochs=70), dist=d)
+                g2(f2, conds, conds_t, fl2, m2, i2, n_total=30, k=k2)                  # (its shapes' tiles: table or tuned here)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                _, inf2 = g2(f2, conds, conds_t, fl2, m2, i2, n_total=30, k=k2)
+                torch.cuda.synchronize(); t1 = time.perf_counter() - t1
+                res["configs1"] = {"workload": "30 frames 960x720, 20 steps, multi_axis, 35+70 epochs (BASELINE.json configs[1])",
+                                   "frames_per_s": 30 / t1, "phase_seconds": {k: round(v, 3) for k, v in inf2["timing"].items()}}
+            except Exception as e:
+                res["configs1"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, a.n_timesteps, not a.no_multi_axis, unet.flops, cfg)
+                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, flops_pass, cfg)
             except Exception as e:  # the baseline must never sink the measurement
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

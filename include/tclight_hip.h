@@ -101,6 +101,13 @@ int tcl_gemm_tune(int cfg, int splits);
  * bit-identical whichever candidate wins (the K-split count is a fixed function of the shape).  0 = static heuristic only and
  * drops the cache. */
 int tcl_gemm_autotune(int enable);
+/* Persistent tile table (text, one line per problem shape).  _load merges a file into the cache (entries are re-validated against each
+ * call's leading dimensions before use); _save writes the cache; _size = entries.  tcl_gemm_autotune(2) = table-only mode: shapes missing
+ * from the table take the static heuristic instead of being timed -- no host synchronisation in the hot loop and the same tile (hence the
+ * same bits, run to run) for a given shape.  tc_light_amd/unet.py loads tc_light_amd/gemm_tune_gfx950.txt at start-up when it exists. */
+int tcl_gemm_tune_save(const char* path);
+int tcl_gemm_tune_load(const char* path);
+size_t tcl_gemm_tune_size(void);
 /* 3x3 Conv2d as implicit GEMM on NHWC: X [B,Hin,Win,Cin], W [Cout, 9*Cin] (tap-major: (ky*3+kx)*Cin + c), Y [B,Hout,Wout,Cout].
  * pad=1: padding 1 (UNet ResnetBlock2D / Downsample2D stride 2); pad=0 with stride 2: the VAE encoder's (0,1,0,1) padding.
  * Hup/Wup > 0: the input is first nearest-upsampled to Hup x Wup (Upsample2D with explicit output size), fused in the gather. */

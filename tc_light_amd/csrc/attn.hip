@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -118,19 +119,24 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) qf[qb][ks] = *(const half8*)(qrow + ks * 16);
     }
-    // DMA: piece p = wid + 4 i covers stage bytes [1024 p, 1024 p + 1024); K image first, V^T image behind it
-    int poff[NPW];
+    // DMA: piece p = wid + 4 i covers stage bytes [1024 p, 1024 p + 1024); K image first, V^T image behind it.  Everything that does not
+    // depend on the tile is computed once: per piece a per-lane source pointer for tile 0 and a per-lane stride per tile (KBYTES, VBYTES,
+    // or 0 for the zero filler behind the images), so issuing a piece costs one 64-bit multiply-add (the selects this replaces were 76
+    // vector instructions per pair of tiles in a loop that is bound by VALU issue).
+    const char* psrc[NPW];
+    int pstr[NPW];
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) poff[i] = (wid + 4 * i) * 1024 + lane * 16;
+    for (int i = 0; i < NPW; ++i) {
+        const int o_ = (wid + 4 * i) * 1024 + lane * 16;
+        psrc[i] = o_ < KBYTES ? kbase + o_ : (o_ < SBYTES ? vbase + (o_ - KBYTES) : zero);
+        pstr[i] = o_ < KBYTES ? KBYTES : (o_ < SBYTES ? VBYTES : 0);
+    }
 #define FLASH_ISSUE(IT)                                                                                                       \
     {                                                                                                                         \
-        const char* kt_ = kbase + (long)(IT) * KBYTES;                                                                        \
-        const char* vt_ = vbase + (long)(IT) * VBYTES;                                                                        \
-        char* st_ = smem + ((IT) % NSTG) * SSTRIDE;                                                                              \
+        char* st_ = smem + ((IT) % NSTG) * SSTRIDE;                                                                           \
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
-            const int o_ = poff[i];                                                                                           \
-            const char* src_ = o_ < KBYTES ? kt_ + o_ : (o_ < SBYTES ? vt_ + (o_ - KBYTES) : zero);                           \
-            char* dst_ = (wid + 4 * i) < NPIECE ? st_ + (wid + 4 * i) * 1024 : smem + NSTG * SSTRIDE;                            \
+            const char* src_ = psrc[i] + (long)(IT) * pstr[i];                                                                \
+            char* dst_ = (wid + 4 * i) < NPIECE ? st_ + (wid + 4 * i) * 1024 : smem + NSTG * SSTRIDE;                         \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
                                              (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                        \
         }                                                                                                                     \
@@ -147,10 +153,12 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
             for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
     }
 
-    auto tile = [&](const int it) __attribute__((always_inline)) {
+    // MK = std::true_type: the tile may hold padded keys (only the last one does).  A compile-time switch, not `if (it >= nfull)`: hipcc turns
+    // that runtime test into 126 unconditional v_cmp / v_cndmask / v_add per tile -- half of this VALU-bound loop's vector instructions.
+    auto tile = [&](const int it, auto MK) __attribute__((always_inline)) {
         const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
         const _Float16* vt = kt + KV_TILE * KS;
-        const bool mask = __builtin_amdgcn_readfirstlane((int)(it >= nfull));
+        constexpr bool mask = decltype(MK)::value;
         half8 kf[2][NQK];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
                 for (int ks = 0; ks < NQK; ++ks) sacc[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[blk][ks], qf[qb][ks], sacc[qb][blk], 0, 0, 0);
             }
-        if (mask) {                                    // scalar branch: only the last tile has padded keys
+        if constexpr (mask) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -192,6 +200,8 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
                 // MFMA already returned s - m and the common path is exp2 alone.  Any shift works as long as every key of the row uses
                 // the same one between rescales; it is re-based when the row maximum climbs more than 2^6 above it (and on tile 0).
                 if (it == 0 || __any(mx > 6.f)) {
+                    asm volatile("; rebase" ::: "memory");       // keeps this rare path a real branch (hipcc otherwise runs the 32 multiplies and
+                                                                 // 32 subtractions below on every tile with alpha = 1 / delta = 0 selected in)
                     const float mn = (float)(_Float16)(m[qb] + (it == 0 ? mx : fmaxf(mx, 0.f)));
                     const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
                     m[qb] = mn;
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
                     for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
             } else {
                 if (__any(mx > m[qb] + 6.f)) {             // lazy rescale (rare after the first tiles)
+                    asm volatile("; rescale" ::: "memory");      // a real branch, see above
                     const float mn = fmaxf(m[qb], mx), alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
                     m[qb] = mn;
                     lsum[qb] *= alpha;
@@ -245,13 +256,22 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
         static_assert(NSTG == 4, "two tiles per barrier need a 4-slot ring");
         FLASH_ISSUE(0);
         if (nt > 1) FLASH_ISSUE(1);
-        for (int it = 0; it < nt; it += 2) {
+        int it = 0;
+        for (; it + 1 < nfull; it += 2) {             // pairs of tiles without padded keys: the hot loop
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // tiles it, it+1 landed for every wave; everyone is done with it-2, it-1
             if (it + 2 < nt) FLASH_ISSUE(it + 2);
             if (it + 3 < nt) FLASH_ISSUE(it + 3);
-            tile(it);
-            if (it + 1 < nt) tile(it + 1);
+            tile(it, std::false_type{});
+            tile(it + 1, std::false_type{});
+        }
+        for (; it < nt; it += 2) {                    // the last one or two tiles (same ring protocol), masked variant
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (it + 2 < nt) FLASH_ISSUE(it + 2);
+            if (it + 3 < nt) FLASH_ISSUE(it + 3);
+            tile(it, std::true_type{});
+            if (it + 1 < nt) tile(it + 1, std::true_type{});
         }
     } else {
         // ring of NSTG slots, prefetch distance NSTG - 1: tile it+NSTG-1 goes into the slot tile it-1 just left
@@ -262,7 +282,8 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // every wave's pieces of tile it landed; everyone is done with tile it-1
             if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);
-            tile(it);
+            if (it < nfull) tile(it, std::false_type{});
+            else tile(it, std::true_type{});
         }
     }
 #undef FLASH_ISSUE
@@ -297,8 +318,22 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 
 // ---- optional in-library timing of the flash kernel (bench.py roofline leg): HIP events recorded on the launch stream
 #include <vector>
-struct FlashProf { bool on = false; int dfilter = 0; std::vector<hipEvent_t> ev; double flops = 0.0; long launches = 0; };
+#include <deque>
+struct FlashProf { bool on = false; int dfilter = 0; std::deque<hipEvent_t> ev; double flops = 0.0, ms = 0.0; long launches = 0; };
 static FlashProf g_prof;
+// resolve (elapsed time -> g_prof.ms) and free the oldest event pairs: all of them (blocking) or only those already complete
+static void flash_prof_drain(bool all) {
+    while (g_prof.ev.size() >= 2) {
+        hipEvent_t e0 = g_prof.ev[0], e1 = g_prof.ev[1];
+        if (all) (void)hipEventSynchronize(e1);
+        else if (hipEventQuery(e1) != hipSuccess) break;
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        g_prof.ms += t;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        g_prof.ev.pop_front(); g_prof.ev.pop_front();
+    }
+}
 
 template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
@@ -310,7 +345,10 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+    if (prof) {
+        if (g_prof.ev.size() > 8192) flash_prof_drain(false);       // a 300-frame pass has ~1e5 launches: keep the live event count bounded
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
+    }
     hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
@@ -321,18 +359,12 @@ static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 extern "C" {
 
 // Timing of the flash kernel launches (all head dims, or only head_dim == dfilter) with HIP events on their stream.
-int tcl_flash_profile_begin(int dfilter) { g_prof.on = true; g_prof.dfilter = dfilter; g_prof.flops = 0.0; g_prof.launches = 0; g_prof.ev.clear(); return TCL_OK; }
+int tcl_flash_profile_begin(int dfilter) { g_prof.on = true; g_prof.dfilter = dfilter; g_prof.flops = 0.0; g_prof.ms = 0.0; g_prof.launches = 0; g_prof.ev.clear(); return TCL_OK; }
 // -> total kernel ms, algorithmic FLOPs (4*B*H*Tq*Tk*d per launch) and launch count since begin; synchronises the events.
 int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches) {
     TCL_CHECK_ARG(total_ms && total_flops && launches);
-    double ms = 0.0;
-    for (size_t i = 0; i + 1 < g_prof.ev.size(); i += 2) {
-        float t = 0.f;
-        (void)hipEventSynchronize(g_prof.ev[i + 1]);
-        (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
-        ms += t;
-        (void)hipEventDestroy(g_prof.ev[i]); (void)hipEventDestroy(g_prof.ev[i + 1]);
-    }
+    flash_prof_drain(true);
+    const double ms = g_prof.ms;
     *total_ms = ms; *total_flops = g_prof.flops; *launches = g_prof.launches;
     g_prof.on = false; g_prof.ev.clear();
     return TCL_OK;

@@ -16,6 +16,7 @@
 // Blocks are laid out XCD-aware: XCD x owns M-tiles == x (mod 8) and walks N-tiles fastest so the A tile
 // stays in that XCD's L2 while W (small) is L2-resident everywhere.
 #include "common.h"
+#include <stdio.h>
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
 #include <unordered_map>
@@ -576,7 +577,13 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
         return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     const TuneKey key = {cp.conv, M, N, K, act, (int)hasr, cp.Hin, cp.Win, cp.Cin, cp.stride, cp.Hup};
     auto it = g_tune_cache.find(key);
-    if (it != g_tune_cache.end()) return run_cfg(it->second, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    if (it != g_tune_cache.end()) {
+        // the key leaves the leading dimensions out: a cached (or file-loaded) tile is re-validated for this call's ldc / ldr
+        const int c = cfg_ok(it->second, M, N, K, ldc, ldr, hasr, act, cp) ? it->second : fallback;
+        return run_cfg(c, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
+    if (g_autotune == 2)      // table-only mode: shapes the loaded table does not know take the static heuristic (no timing, no host sync)
+        return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs
     int cand[9], nc = 0;
     const int t128 = cdiv(M, 128) * cdiv(N, 128);
@@ -620,6 +627,36 @@ extern "C" {
 int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = ws ? bytes : 0; return TCL_OK; }
 int tcl_gemm_tune(int cfg, int splits) { g_tune_cfg = cfg; g_tune_splits = splits; return TCL_OK; }
 int tcl_gemm_autotune(int enable) { g_autotune = enable; if (!enable) g_tune_cache.clear(); return TCL_OK; }
+
+// Persistent tuning table: one text line per problem shape, "conv M N K act hasr Hin Win Cin stride Hup cfg".
+int tcl_gemm_tune_save(const char* path) {
+    TCL_CHECK_ARG(path);
+    FILE* f = fopen(path, "w");
+    if (!f) return TCL_EINVAL;
+    fprintf(f, "# tc_light_amd GEMM tile table, gfx950: conv M N K act hasr Hin Win Cin stride Hup -> cfg (csrc/gemm.hip)\n");
+    for (const auto& kv : g_tune_cache) {
+        const TuneKey& k = kv.first;
+        fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d\n", k.conv, k.M, k.N, k.K, k.act, k.hasr, k.Hin, k.Win, k.Cin, k.stride, k.Hup, kv.second);
+    }
+    fclose(f);
+    return TCL_OK;
+}
+int tcl_gemm_tune_load(const char* path) {
+    TCL_CHECK_ARG(path);
+    FILE* f = fopen(path, "r");
+    if (!f) return TCL_EINVAL;
+    char line[256];
+    while (fgets(line, sizeof line, f)) {
+        TuneKey k; int cfg;
+        if (line[0] == '#') continue;
+        if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d %d", &k.conv, &k.M, &k.N, &k.K, &k.act, &k.hasr, &k.Hin, &k.Win, &k.Cin, &k.stride, &k.Hup, &cfg) != 12) continue;
+        if (!((cfg >= 1 && cfg <= 8) || cfg == 11)) continue;          // only ids the cached path may run
+        g_tune_cache[k] = cfg;
+    }
+    fclose(f);
+    return TCL_OK;
+}
+size_t tcl_gemm_tune_size(void) { return g_tune_cache.size(); }
 
 int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int act, hipStream_t st) {

@@ -20,6 +20,8 @@ _ERR = {1: "TCL_EINVAL (bad argument / unsupported shape)", 2: "TCL_ELAUNCH (HIP
 
 def _ctype(decl):
     decl = decl.strip()
+    if decl.startswith("const char*") or decl.startswith("const char *"):
+        return ctypes.c_char_p
     if "*" in decl or decl.startswith("hipStream_t"):
         return ctypes.c_void_p
     if decl.startswith("size_t"):
@@ -39,7 +41,7 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
     for ret, name, args in re.findall(r"\b(int|size_t)\s+(tcl_\w+)\s*\(([^)]*)\)\s*;", src):
-        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_size_t, [_ctype(a) for a in args.split(",") if a.strip()])
+        out[name] = (ctypes.c_int if ret == "int" else ctypes.c_size_t, [_ctype(a) for a in args.split(",") if a.strip() and a.strip() != "void"])
     return out
 
 
@@ -62,7 +64,7 @@ class _Lib:
         res = sig[0]
 
         def call(*a):
-            conv = [x.data_ptr() if isinstance(x, torch.Tensor) else x for x in a]
+            conv = [x.data_ptr() if isinstance(x, torch.Tensor) else (x.encode() if isinstance(x, str) else x) for x in a]
             r = fn(*conv)
             if res is ctypes.c_int and r != 0:
                 raise RuntimeError(f"{name} failed: {_ERR.get(r, r)}")

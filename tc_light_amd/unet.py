@@ -33,6 +33,27 @@ def _conv_w(w, dev):          # [Cout,Cin,3,3] -> [Cout, 9*Cin] tap-major
     return _dev(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), dev)
 
 
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.txt")
+
+
+def load_gemm_table(L):
+    """The committed GEMM tile table (shape -> tile configuration, measured on an MI355X by `bench.py --save_gemm_table`): loaded once per
+    process, so known shapes never pay the in-call autotuner (no host sync in the hot loop, same tile run to run).  TCL_GEMM_TABLE overrides
+    the path; TCL_AUTOTUNE = 1 (default: time shapes the table lacks on first use), "table" (never time: static heuristic for missing
+    shapes) or 0 (static heuristic only).  Results are bit-identical whatever tile is chosen (tests/test_gpu_kernels.py)."""
+    if getattr(load_gemm_table, "done", False):
+        return
+    load_gemm_table.done = True
+    mode = os.environ.get("TCL_AUTOTUNE", "1")
+    if mode == "0":
+        L.tcl_gemm_autotune(0)
+        return
+    path = os.environ.get("TCL_GEMM_TABLE", GEMM_TABLE)
+    if os.path.exists(path):
+        L.tcl_gemm_tune_load(path)
+    L.tcl_gemm_autotune(2 if mode == "table" else 1)
+
+
 class Ops:
     """Thin typed wrappers around the C ABI (allocation via torch's caching allocator, launches on the current stream)."""
     _splitk_ws = {}
@@ -40,6 +61,7 @@ class Ops:
     def __init__(self, dev):
         self.dev = dev
         self.L = lib()
+        load_gemm_table(self.L)
         self._gn_ws = {}
         ws = Ops._splitk_ws.get(str(dev))
         if ws is None:      # one split-K scratch per device, registered with the library (single compute stream)

@@ -34,6 +34,9 @@ def ws_bytes(n):
 
 @pytest.mark.parametrize("d,B,Tq,Tk,kv_div", [
     (40, 2, 35640, 35640, 1),      # level-0 self-attention over one merged 4-frame chunk + bank (two-query-block kernel, 4-slot ring)
+    (40, 2, 47520, 47520, 1),      # the same at BASELINE config 3 (1280x720: 31 680 local + bank); even count of full tiles + 1 masked
+    (40, 2, 16400, 17000, 1),      # two-query-block kernel with an ODD count of full key tiles + a masked one (tail loop takes two tiles)
+    (40, 2, 16400, 16448, 1),      # ... and with no padded keys at all (257 full tiles: the tail loop takes the last full tile alone)
     (40, 8, 10800, 154, 4),        # level-0 text cross-attention, context shared by the 4 frames of a chunk
     (80, 2, 8910, 8910, 1),        # level-1 self-attention
     (160, 8, 690, 690, 1)])        # level-2 self-attention (no merging)
@@ -58,6 +61,35 @@ def test_attention_full_size_sampled_rows(L, d, B, Tq, Tk, kv_div):
     L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, ones, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 1, wq, wkv, st())
     assert (o.float() - 1).abs().max().item() < 2e-3
     assert torch.isfinite(o).all()
+
+
+def test_attention_rebase_path_spiked_scores(L):
+    """The lazy rebase of the running softmax shift (attn.hip: taken on tile 0 and whenever a row maximum climbs > 2^6 above the shift) is a
+    rare, data-dependent branch that random data never takes after tile 0 (cdna_hip_programming.md T13 hazard).  Spike some (query, key)
+    pairs so that the maximum jumps at chosen LATE tiles -- in the first and in the second tile of a barrier pair, in both query blocks of a
+    wave, and in the masked tail tile -- and compare those rows (and their wave neighbours) with an f32 reference."""
+    d, B, Tq, Tk, Hh = 40, 2, 16400, 16950, 8
+    C = Hh * d
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    k = torch.randn(B, Tk, C, device="cuda", generator=g).to(H)
+    v = torch.randn(B, Tk, C, device="cuda", generator=g).to(H)
+    spikes = [(5, 64 * 100 + 3), (37, 64 * 101 + 9), (70, 64 * 200 + 1), (300, 64 * 7 + 60), (8000, Tk - 2), (8001, 64 * 264 + 5), (16399, 64 * 150)]
+    for qi, kj in spikes:                                   # q.k * scale * log2(e) ~ 9 * |q|^2 / sqrt(40) * 1.44 >> 2^6 above the running shift
+        k[:, kj] = (q[:, qi].float() * 9.0).to(H)
+    o = torch.zeros(B, Tq, C, device="cuda", dtype=H)
+    wq, wkv = ws_bytes(L.tcl_attention_q_bytes(B, Hh, Tq, d)), ws_bytes(L.tcl_attention_kv_bytes(B, Hh, Tk, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, 1, 1, wq, wkv, st())
+    rows = sorted({r for qi, _ in spikes for r in range(max(qi - 33, 0), min(qi + 34, Tq))})
+    rows = torch.tensor(rows, device="cuda")
+    qq = q[:, rows].float().view(B, -1, Hh, d).transpose(1, 2)
+    kk, vv = (t.float().view(B, Tk, Hh, d).transpose(1, 2) for t in (k, v))
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, -1, C)
+    assert torch.isfinite(o).all()
+    assert rel(o[:, rows], ref) < 3e-3
+    sp = torch.tensor([qi for qi, _ in spikes], device="cuda")
+    pos = torch.searchsorted(rows, sp)
+    assert rel(o[:, sp], ref[:, pos]) < 3e-3               # the spiked rows themselves: output ~ v[kj] (one key dominates)
 
 
 @pytest.mark.parametrize("na,nb,C,ratio", [(32400, 10800, 320, 0.6),     # local (random-frame) merge of a 4-frame chunk at level 0

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
     constexpr int NPIECE = (SBYTES + 1023) / 1024, NPW = (NPIECE + 3) / 4, SSTRIDE = NPIECE * 1024;
     constexpr bool LROW = DPV > D;
     constexpr bool FOLD = DP > D && LROW && (D % 16 == 8);        // spare Q/K column D: lanes hl == 1, element 0 of fragment D/16
+    constexpr bool PVQ = QB > 1;                                  // PV per query block right behind its softmax (V^T fragments held in registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
 
     const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
@@ -165,6 +166,15 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
             for (int ks = 0; ks < NQK; ++ks) kf[blk][ks] = *(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16);
         half8 pf[QB][2][2];
+        half8 vfr[PVQ ? 2 : 1][2][NDT];               // PVQ: every V^T fragment of the tile in registers (read once, early)
+        if constexpr (PVQ) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                    for (int t = 0; t < NDT; ++t) vfr[blk][ss][t] = *(const half8*)(vt + (ql + t * 32) * V_STRIDE + blk * 32 + 16 * ss + 8 * hl);
+        }
         // all QK^T MFMAs of the tile first (QB * 2 * NQK back to back): the row-maximum VALU work of query block 0 then runs under the
         // MFMAs of query block 1 still in the pipe, instead of each block's maximum waiting for its own MFMAs with the pipe idle
         float16v sacc[QB][2];
@@ -185,43 +195,47 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) sacc[qb][blk][r] = -1e30f; }
         }
+        // row maxima of every query block first, then ONE (rare) branch for all re-basing of the tile, so that the common path below --
+        // exponentials, conversions and the PV MFMAs of all query blocks -- is a single basic block the scheduler can interleave
+        float mxq[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            float16v (&s)[2] = sacc[qb];
-            float mx = s[0][0];
+            float mx = sacc[qb][0][0];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-            mx = xhalf_max(mx);
-            float ps = 0.f;
-            if (FOLD) {
-                // The running shift m (kept f16-representable) rides in the spare Q column D against a ones column of the K panel, so the
-                // MFMA already returned s - m and the common path is exp2 alone.  Any shift works as long as every key of the row uses
-                // the same one between rescales; it is re-based when the row maximum climbs more than 2^6 above it (and on tile 0).
-                if (it == 0 || __any(mx > 6.f)) {
-                    asm volatile("; rebase" ::: "memory");       // keeps this rare path a real branch (hipcc otherwise runs the 32 multiplies and
-                                                                 // 32 subtractions below on every tile with alpha = 1 / delta = 0 selected in)
-                    const float mn = (float)(_Float16)(m[qb] + (it == 0 ? mx : fmaxf(mx, 0.f)));
-                    const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
-                    m[qb] = mn;
-                    if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);            // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][blk][r]);
+            mxq[qb] = xhalf_max(mx);
+        }
+        bool need = it == 0;
 #pragma unroll
-                    for (int t = 0; t < NDT; ++t)
+        for (int qb = 0; qb < QB; ++qb) need |= FOLD ? (mxq[qb] > 6.f) : (mxq[qb] > m[qb] + 6.f);
+        if (__any(need)) {
+            asm volatile("; rebase" ::: "memory");       // keeps this rare path a real branch (hipcc otherwise runs the multiplies and
+                                                         // subtractions below on every tile with alpha = 1 / delta = 0 selected in)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+            for (int qb = 0; qb < QB; ++qb) {
+                float16v (&s)[2] = sacc[qb];
+                const float mx = mxq[qb];
+                if constexpr (FOLD) {
+                    // The running shift m (kept f16-representable) rides in the spare Q column D against a ones column of the K panel, so
+                    // the MFMA already returned s - m and the common path is exp2 alone.  Any shift works as long as every key of the row
+                    // uses the same one between rescales; it is re-based when the row maximum climbs more than 2^6 above it (and on tile 0).
+                    if (it == 0 || __any(mx > 6.f)) {
+                        const float mn = (float)(_Float16)(m[qb] + (it == 0 ? mx : fmaxf(mx, 0.f)));
+                        const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
+                        m[qb] = mn;
+                        if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);        // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
+                        for (int t = 0; t < NDT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s[blk][r] -= delta;
-                }
+                            for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
+                        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
-            } else {
-                if (__any(mx > m[qb] + 6.f)) {             // lazy rescale (rare after the first tiles)
-                    asm volatile("; rescale" ::: "memory");      // a real branch, see above
+                            for (int r = 0; r < 16; ++r) s[blk][r] -= delta;
+                    }
+                } else if (__any(mx > m[qb] + 6.f)) {          // lazy rescale (rare after the first tiles)
                     const float mn = fmaxf(m[qb], mx), alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
                     m[qb] = mn;
                     lsum[qb] *= alpha;
@@ -230,25 +244,49 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
                 }
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float16v (&s)[2] = sacc[qb];
+            float ps = 0.f;
+            if (FOLD) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
+            } else {
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - m[qb]); if (!LROW) ps += p; pf[qb][blk][r >> 3][r & 7] = (_Float16)p; }
             }
             if (!LROW) lsum[qb] += ps;
-        }
+            if constexpr (PVQ) {
+                // this query block's PV right behind its softmax: the 4 * NDT MFMAs run while the NEXT block's exponentials issue on the
+                // vector pipe (one wave then overlaps its own matrix and vector work instead of leaving that to its SIMD partner)
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+                for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 8 * hl;
+                    for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-                for (int t = 0; t < NDT; ++t) {
-                    const half8 vf = *(const half8*)(vr + t * 32 * V_STRIDE);
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][blk][ss], o[qb][t], 0, 0, 0);
-                }
+                        for (int t = 0; t < NDT; ++t) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[blk][ss][t], pf[qb][blk][ss], o[qb][t], 0, 0, 0);
             }
+        }
+        if constexpr (!PVQ) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const _Float16* vr = vt + ql * V_STRIDE + blk * 32 + 16 * ss + 8 * hl;
+#pragma unroll
+                    for (int t = 0; t < NDT; ++t) {
+                        const half8 vf = *(const half8*)(vr + t * 32 * V_STRIDE);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][blk][ss], o[qb][t], 0, 0, 0);
+                    }
+                }
+        }
     };
     if constexpr (TPB == 2) {
         // 4-slot ring, two tiles per barrier: tiles it, it+1 are consumed while it+2, it+3 stream into the slots of it-2, it-1 --

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "tclight_hip.h")
-LIB_PATH = os.path.join(_HERE, "libtclight_hip.so")
+LIB_PATH = os.environ.get("TCL_LIB_PATH") or os.path.join(_HERE, "libtclight_hip.so")     # TCL_LIB_PATH: A/B runs of two builds (tools/ab)
 
 _ERR = {1: "TCL_EINVAL (bad argument / unsupported shape)", 2: "TCL_ELAUNCH (HIP error)"}
 

@@ -3,6 +3,7 @@ whole-tensor CPU oracle is out of reach: each kernel is checked through properti
 a plain PyTorch fp32 statement of the same rows, row sums of the softmax, the optimality / counting invariants of the bipartite matching,
 and whole-tensor comparison against torch fp32 matmul / conv2d on the GPU where that still fits.
 Tolerances: f16 in / f32 accumulate / f16 out -> rel-L2 <= 2e-3 per op (3e-3 for attention, whose P is rounded to f16)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -94,7 +95,11 @@ def test_attention_rebase_path_spiked_scores(L):
 
 @pytest.mark.parametrize("na,nb,C,ratio", [(32400, 10800, 320, 0.6),     # local (random-frame) merge of a 4-frame chunk at level 0
                                            (23760, 23760, 320, 0.5),     # global merge against an equally long bank
-                                           (8100, 2700, 640, 0.6)])      # level 1
+                                           (8100, 2700, 640, 0.6),       # level 1
+                                           (43200, 14400, 320, 0.6),     # BASELINE config 3 (1280x720): local merge of a 4-frame chunk, level 0
+                                           (31680, 31680, 320, 0.5),     # config 3: global merge against the bank
+                                           (32400, 10800, 320, 0.9),     # BASELINE config 4 (tclight_bkgd_robotwin.yaml: local 0.9 / global 0.8)
+                                           (14040, 14040, 320, 0.8)])    # config 4: 10800 + 3240 local tokens against an equally long bank
 def test_tome_match_full_size_invariants(L, na, nb, C, ratio):
     g = torch.Generator(device="cuda").manual_seed(na)
     T, Bt = na + nb, 2
@@ -176,10 +181,13 @@ def test_gemm_conv_full_size_vs_torch(L):
         assert (err2 / ref2) ** 0.5 < 2e-3
 
 
-def test_unet_pass_full_size_deterministic():
-    """One block-major UNet pass over ALL chunks of a config-2 step (8 chunks, 30 frames, latent 90x120): finite, and bit-identical when
-    repeated from the same bank state and draws (deterministic GroupNorm, fixed K-split rule, order-free matching keys), with the
-    matching chain on its side stream or on the main stream."""
+@pytest.mark.parametrize("Hh,Ww,Fs,Lt", [(90, 120, [2] + [4] * 7, 154),       # config 2: the 8 xy chunks of a 30-frame step
+                                         (90, 160, [3] + [4] * 9, 154),       # config 3: one rank's 38-frame block (xy chunks at 1280x720)
+                                         (64, 90, [4] * 10, 77)])             # config 3: yt planes of a 64-frame window (64 x 90 "images"), 10 column chunks
+def test_unet_pass_full_size_deterministic(Hh, Ww, Fs, Lt):
+    """One block-major UNet pass over the chunks of a step at BASELINE sizes: finite, and bit-identical when repeated from the same bank
+    state and draws (deterministic GroupNorm, fixed K-split rule, order-free matching keys), with the matching chain on its side stream
+    or on the main stream."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from tc_light_amd import sd15
@@ -188,9 +196,8 @@ def test_unet_pass_full_size_deterministic():
     sd = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
     eng = UNetEngine(sd, "cuda", VidToMe("cuda", seed=1))
     g = torch.Generator(device="cuda").manual_seed(5)
-    text = torch.randn(2, 154, 768, device="cuda", generator=g).half()
-    Fs = [2] + [4] * 7
-    x = torch.randn(2 * sum(Fs), 90, 120, 8, device="cuda", generator=g).half()
+    text = torch.randn(2, Lt, 768, device="cuda", generator=g).half()
+    x = torch.randn(2 * sum(Fs), Hh, Ww, 8, device="cuda", generator=g).half()
     import os
     outs = []
     for k in range(3):
@@ -198,9 +205,132 @@ def test_unet_pass_full_size_deterministic():
             os.environ["TCL_TOME_STREAM"] = "0"          # matching chain on the main stream: same kernels, same data, no overlap
         eng.tome.reset_global_tokens()
         eng.tome.draws = [(min(1, f - 1) if f > 1 else -1, 0.25 + 0.1 * i) for i, f in enumerate(Fs)]
-        outs.append(eng.forward_many(x, Fs, 90, 120, 801.0, text).clone())
+        outs.append(eng.forward_many(x, Fs, Hh, Ww, 801.0, text).clone())
     os.environ.pop("TCL_TOME_STREAM", None)
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])                 # the side-stream schedule changes timing only
+
+
+def test_config3_windows_and_shards():
+    """BASELINE config 3 host logic at size: 300 frames, window 64 -> 5 windows starting [0, 59, 118, 177, 236] with overlaps [5, 5, 5, 5]
+    (generate.py:246-260), frames sharded 38/38/38/38/37/37/37/37, and the per-rank deal of the 5 x 40 yt items covers every
+    (window, column) exactly once."""
+    from tc_light_amd import hostlogic as HL
+    from tc_light_amd.parallel import Dist
+    starts, ovl = HL.temporal_windows(300, 64)
+    assert starts == [0, 59, 118, 177, 236] and ovl == [5, 5, 5, 5]
+    assert [HL.shard_range(300, r, 8)[1] - HL.shard_range(300, r, 8)[0] for r in range(8)] == [38] * 4 + [37] * 4
+    items = [(sl, k) for sl in starts for k in range(40)]
+    seen = sorted(it for r in range(8) for it in Dist(r, 8).my_items(items))
+    assert seen == sorted(items)
+    assert max(len(Dist(r, 8).my_items(items)) for r in range(8)) == 25
+
+
+def _gpu_tracks(n, h, w, reuse, seed):
+    """synth.track_ids on the device (the numpy version takes a minute at 300 x 1280 x 720): frame k re-uses frame k-1's ids shifted by one
+    pixel with probability `reuse`, fresh ids otherwise; ids are unique within a frame like get_flowid's."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ids = torch.empty(n, h, w, dtype=torch.int64, device="cuda")
+    ids[0] = torch.arange(h * w, device="cuda").view(h, w)
+    last = h * w
+    for k in range(1, n):
+        fresh = torch.rand(h, w, device="cuda", generator=g) > reuse
+        fresh[:, 0] = True
+        cur = torch.roll(ids[k - 1], 1, dims=1)
+        cnt = int(fresh.sum())
+        cur[fresh] = last + torch.arange(cnt, device="cuda")
+        last += cnt
+        ids[k] = cur
+    return ids.reshape(-1).to(torch.int32), last
+
+
+def test_config5_stage2_full_size_properties():
+    """BASELINE config 5 (stage 2 only, 300 x 1280 x 720, K >= 1e8 codebook rows) through size-independent properties of
+    tcl_unique_tensor_opt / tcl_unique_tensor_grad (the oracle would need hours here):
+      * zero iterations: the final gather of the scatter-mean initialised codebook reproduces, per pixel, the mean of its track;
+      * one iteration moves exactly the rows of the mini-batch's frames (cur and prev) -- Adam's first step is +-lr where the gradient is
+        non-zero and 0 elsewhere -- and every moved row moves by at most lr (SH units);
+      * the iteration-level C entry point + tcl_adam_step reproduces the whole-stage driver (same kernels, 1e-6);
+      * three iterations keep everything finite and lower the loss on a repeated batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tc_light_amd import post_opt as P
+    from tc_light_amd.lib import lib
+    L = lib()
+    n, h, w = 300, 720, 1280
+    inv, k = _gpu_tracks(n, h, w, reuse=0.6, seed=3)
+    assert k >= 100_000_000 and k < 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(1)
+    base = torch.rand(1, 3, h + 8, w + 300, device="cuda", generator=g)
+    base = torch.nn.functional.avg_pool2d(base, 9, stride=1, padding=4)
+    ed = torch.stack([base[0, :, 4:4 + h, i:i + w] for i in range(n)]).contiguous()        # frame i = the base shifted by i px (matches the ids' shift)
+    ed = (ed * (1 + 0.03 * torch.randn(n, 3, 1, 1, device="cuda", generator=g)) + 0.01 * torch.randn(ed.shape, device="cuda", generator=g)).clamp_(0, 1)
+    flows = torch.zeros(n, 2, h, w, device="cuda"); flows[1:, 0] = -1.0        # frame i (x) = frame i-1 (x - 1)
+    masks = torch.ones(n, 1, h, w, device="cuda")
+    ds = P.OptDataset(ed, flows, masks, device="cuda")
+    # ---- zero iterations
+    out0, feat0, _ = P.unique_tensor_optimization(ds, inv, np.zeros((0, 16), np.int32), batch_size=16, k=k)
+    feat0 = feat0.t().contiguous().clone()                                     # planar [3,K]
+    cnt = torch.bincount(inv.long(), minlength=k).float()
+    for c in range(3):
+        mean = torch.zeros(k, device="cuda").index_add_(0, inv.long(), ed[:, c].reshape(-1)) / cnt.clamp_min(1)
+        assert (out0[:, c].reshape(-1) - mean[inv.long()].clamp(0, 1)).abs().max().item() < 2e-5
+    del out0
+    # ---- one iteration
+    batch = np.array([[17, 250, 3, 120, 299, 64, 180, 1, 33, 90, 210, 5, 270, 150, 44, 0]], np.int32)
+    _, feat1, l1 = P.unique_tensor_optimization(ds, inv, batch, batch_size=16, k=k)
+    feat1 = feat1.t().contiguous()
+    moved = ((feat1 - feat0).abs() > 0).any(0)
+    frames_touched = sorted({int(f) for f in batch[0]} | {max(int(f) - 1, 0) for f in batch[0]})
+    touched = torch.zeros(k, dtype=torch.bool, device="cuda")
+    for f in frames_touched:
+        touched[inv[f * h * w:(f + 1) * h * w].long()] = True
+    assert not (moved & ~touched).any()                                        # rows outside the batch's frames did not move
+    assert moved.float().sum().item() > 0.5 * touched.float().sum().item()
+    lr = 0.05 * 16 / n
+    assert (feat1 - feat0).abs().max().item() <= lr * 1.0001
+    assert torch.isfinite(l1).all()
+    # ---- iteration-level API == whole-stage driver
+    from tc_light_amd.lib import stream
+    feat = feat0.clone()
+    gbuf, m, v = (torch.zeros_like(feat) for _ in range(3))
+    cat = torch.from_numpy(np.concatenate([batch[0], np.maximum(batch[0] - 1, 0)]).astype(np.int32)).cuda()
+    ws = torch.empty(L.tcl_stage_workspace_bytes(16, h, w), dtype=torch.uint8, device="cuda")
+    lp = torch.zeros(1, device="cuda")
+    L.tcl_unique_tensor_grad(ds.edited_images, flows, masks, inv, n, h, w, k, cat, 16, 16, 15, 0.2, 0.8, 0.05, feat, gbuf, lp, ws, stream())
+    L.tcl_adam_step(feat, gbuf, m, v, 3 * k, lr, 0.9, 0.999, 1e-15, 1, stream())
+    assert abs(float(lp) - float(l1[0])) < 2e-5 * abs(float(l1[0]))
+    d = (feat - feat1).abs()
+    assert (d > 1e-6).float().mean().item() < 1e-3                             # float-atomic order: a few rounding-noise rows take +-lr
+    del feat, gbuf, m, v, feat1
+    # ---- three iterations on one batch: finite, decreasing
+    _, f3, l3 = P.unique_tensor_optimization(ds, inv, np.repeat(batch, 3, 0), batch_size=16, k=k)
+    assert torch.isfinite(l3).all() and torch.isfinite(f3).all() and float(l3[2]) < float(l3[0])
+
+
+def test_config4_background_blend_full_size():
+    """BASELINE config 4 geometry: prepare_data's matte + blend at 960x720 (the RMBG input is 1152x896 through the reference's transposed
+    resize, generate.py:151-153) against the oracle's matte on 2 of the frames; local 0.9 / global 0.8 matching is covered by
+    test_tome_match_full_size_invariants."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from types import SimpleNamespace
+    from oracle import rmbg as OR
+    from tc_light_amd.generate import Generator
+    from tc_light_amd.rmbg import RMBGEngine, random_state_dict
+    sd = random_state_dict(3)
+    eng = RMBGEngine(sd, "cuda")
+    stub = SimpleNamespace(dev=torch.device("cuda"), tome=SimpleNamespace(args=dict(target_stride=4)))
+    gen = Generator(stub, None, dict(noise_mode="same", local_merge_ratio=0.9, global_merge_ratio=0.8), rmbg=eng)
+    assert gen.unet.tome.args["local_merge_ratio"] == 0.9 and gen.unet.tome.args["global_merge_ratio"] == 0.8
+    import synth
+    fr = synth.video_clip(2, 720, 960, seed=9)["frames"]
+    bg = torch.from_numpy(np.random.default_rng(1).random((1, 3, 720, 960)).astype(np.float32))
+    gen.prepare_data(fr.cuda(), background=bg.cuda())
+    with torch.no_grad():
+        alpha = OR.estimate_alpha(sd, fr)
+    err = (gen.frames.cpu() - (alpha * fr + (1 - alpha) * bg)).abs()
+    assert err.max().item() < 2e-3 and err.mean().item() < 5e-5, (err.max().item(), err.mean().item())
+    assert gen.init_noise.shape == (2, 4, 90, 120)

@@ -120,26 +120,26 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) qf[qb][ks] = *(const half8*)(qrow + ks * 16);
     }
-    // DMA: piece p = wid + 4 i covers stage bytes [1024 p, 1024 p + 1024); K image first, V^T image behind it.  Everything that does not
-    // depend on the tile is computed once: per piece a per-lane source pointer for tile 0 and a per-lane stride per tile (KBYTES, VBYTES,
-    // or 0 for the zero filler behind the images), so issuing a piece costs one 64-bit multiply-add (the selects this replaces were 76
-    // vector instructions per pair of tiles in a loop that is bound by VALU issue).
-    const char* psrc[NPW];
-    int pstr[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int o_ = (wid + 4 * i) * 1024 + lane * 16;
-        psrc[i] = o_ < KBYTES ? kbase + o_ : (o_ < SBYTES ? vbase + (o_ - KBYTES) : zero);
-        pstr[i] = o_ < KBYTES ? KBYTES : (o_ < SBYTES ? VBYTES : 0);
-    }
+    // DMA: piece p = wid + 4 i covers stage bytes [1024 p, 1024 p + 1024); K image first, V^T image behind it.  The piece index is
+    // wave-uniform and the K / V^T boundary is piece-aligned (KBYTES = 128 KS, 8 | KS), so a piece's source is a SCALAR base (s_cselect
+    // between the two panels) plus the one per-lane offset lane * 16 -- no per-lane selects, no per-piece address registers (an earlier
+    // version spent 76 vector instructions per pair of tiles on those selects; a per-piece pointer table spilled the d >= 80 kernels).
+    // Only a V^T image that is not a multiple of 1 KiB (DPV = 96) needs the per-lane zero filler behind its end.
+    static_assert(KBYTES % 1024 == 0, "K image must be piece-aligned");
+    const int lane16 = lane * 16;
+    __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
 #define FLASH_ISSUE(IT)                                                                                                       \
     {                                                                                                                         \
-        char* st_ = smem + ((IT) % NSTG) * SSTRIDE;                                                                           \
+        const char* kt_ = kbase + (long)(IT) * KBYTES;                                                                        \
+        const char* vt_ = vbase + (long)(IT) * VBYTES;                                                                        \
+        const int st_ = ((IT) % NSTG) * SSTRIDE;                                                                              \
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
-            const char* src_ = psrc[i] + (long)(IT) * pstr[i];                                                                \
-            char* dst_ = (wid + 4 * i) < NPIECE ? st_ + (wid + 4 * i) * 1024 : smem + NSTG * SSTRIDE;                         \
+            const int pb_ = (wid + 4 * i) * 1024;                                                                             \
+            const char* src_ = (pb_ < KBYTES ? kt_ + pb_ : vt_ + (pb_ - KBYTES)) + lane16;                                    \
+            if (SBYTES % 1024 != 0 || NPW * 4 != NPIECE) src_ = pb_ + lane16 < SBYTES ? src_ : zero + lane16;                 \
+            const int dst_ = (wid + 4 * i) < NPIECE ? st_ + pb_ : NSTG * SSTRIDE;      /* pieces past the stage: 1 KiB dump */  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
-                                             (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                        \
+                                             (__attribute__((address_space(3))) void*)(lds0 + dst_), 16, 0, 0);               \
         }                                                                                                                     \
     }
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) need |= FOLD ? (mxq[qb] > 6.f) : (mxq[qb] > m[qb] + 6.f);
         if (__any(need)) {
-            asm volatile("; rebase" ::: "memory");       // keeps this rare path a real branch (hipcc otherwise runs the multiplies and
+            asm volatile("; rebase");       // keeps this rare path a real branch (hipcc otherwise runs the multiplies and
                                                          // subtractions below on every tile with alpha = 1 / delta = 0 selected in)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
@@ -315,14 +315,20 @@ __global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void 
         // ring of NSTG slots, prefetch distance NSTG - 1: tile it+NSTG-1 goes into the slot tile it-1 just left
         FLASH_ISSUE(0);
         if (NSTG == 3 && nt > 1) FLASH_ISSUE(1);
-        for (int it = 0; it < nt; ++it) {
-            if (NSTG == 3 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();             // every wave's pieces of tile it landed; everyone is done with tile it-1
-            if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);
-            if (it < nfull) tile(it, std::false_type{});
-            else tile(it, std::true_type{});
+        // (two loops over the same ring protocol -- full tiles, then the at most one tile with padded keys -- so that the hot loop holds
+        // only the unmasked body: with both bodies in one loop hipcc's hoisted addressing spilled the d >= 80 kernels)
+#define FLASH_STEP(MK)                                                                                                        \
+        {                                                                                                                     \
+            if (NSTG == 3 && it + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                          \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+            __builtin_amdgcn_s_barrier();             /* every wave's pieces of tile it landed; everyone is done with it-1 */ \
+            if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);                                                               \
+            tile(it, MK);                                                                                                     \
         }
+        int it = 0;
+        for (; it < nfull; ++it) FLASH_STEP(std::false_type{})
+        for (; it < nt; ++it) FLASH_STEP(std::true_type{})
+#undef FLASH_STEP
     }
 #undef FLASH_ISSUE
     // ---- epilogue

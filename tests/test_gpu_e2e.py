@@ -10,8 +10,10 @@ test_multi_axis_bank_carry_over = a small multi-axis run with VidToMe ON: pins t
 
 Tolerances (north_star: 1e-3 rel-L2 on the output).  The engine computes in f16 with f32 accumulation, the oracle in f32; the UNet/VAE
 arithmetic of the oracle is parity-unpinned w.r.t. diffusers (oracle/sd15.py header).  With the engine's merge maps injected into the
-oracle the final frames must agree to 1e-3 rel-L2 (asserted); with the oracle's own matching the discrete decisions differ on near-tied
-f16 scores and the figure is printed and bounded loosely.
+oracle the relit frames out of denoise + decode agree to 1e-3 rel-L2 (measured 9.9e-4, asserted < 1.2e-3).  Stage 1/2 then run 105 Adam
+iterations whose update is +-lr regardless of the gradient's size: the oracle run twice with inputs differing by 1e-7 ends 1.3e-2 apart
+(measured in the test), so after stage 2 the assertion is "within 1.5x the oracle's own self-distance" plus agreement of every
+iteration's loss.  With the oracle's own matching the discrete decisions differ on near-tied f16 scores: figure printed, bounded loosely.
 """
 import os
 import time
@@ -85,9 +87,14 @@ def test_config1_end_to_end():
     # the conditioning of the reference's algorithm (Adam's first steps are +-lr whatever the gradient's size: 0.05*16/8 * C0 = 0.028 RGB per
     # step here, so a 1e-3 input difference is amplified -- the oracle fed with 1e-3-perturbed inputs moves by 1.2-1.4e-2 rel-L2 itself)
     _, final_h, _, _ = E.oracle_post_opt(stages["clean"].cpu(), d["past_flows"], d["masks"], inv, c, n)
+    # ... and the oracle against ITSELF with its input perturbed at the f32 rounding level (1e-7 relative): the reference's optimiser is
+    # chaotic at the pixel level -- Adam's update is +-lr whatever the gradient's size, so rounding noise decides the sign wherever the
+    # gradient nearly cancels and 105 iterations spread that -- which bounds what ANY two implementations can agree to after stage 2
+    g7 = torch.Generator().manual_seed(1)
+    _, final_p, _, _ = E.oracle_post_opt((clean_i * (1 + 1e-7 * torch.randn(clean_i.shape, generator=g7))).clamp(0, 1), d["past_flows"], d["masks"], inv, c, n)
     t_all = time.time() - t0
     r = dict(encode=E.rel(stages["cc"].cpu(), cc), latents=E.rel(stages["lat"].cpu(), lat_i), decoded=E.rel(stages["clean"].cpu(), clean_i),
-             final_same_decoded=E.rel(out.cpu(), final_h), final=E.rel(out.cpu(), final_i), oracle_conditioning=E.rel(final_h, final_i))
+             final_same_decoded=E.rel(out.cpu(), final_h), final=E.rel(out.cpu(), final_i), oracle_vs_oracle_1e7=E.rel(final_p, final_i))
     print(f"[e2e config 1, injected maps] HIP {t_hip:.1f} s (cold) vs oracle {t_all:.0f} s on {torch.get_num_threads()} threads (denoise+VAE {t_den:.0f} s); "
           f"rel-L2: " + ", ".join(f"{k_} {v:.2e}" for k_, v in r.items()))
     l1h, l2h = info["losses_exposure"].cpu().numpy(), info["losses_unique"].cpu().numpy()
@@ -97,8 +104,11 @@ def test_config1_end_to_end():
     print(f"[e2e config 1] final vs oracle-from-same-decoded: median |diff| {dd.median().item():.2e}, fraction > 1e-2: {(dd > 1e-2).float().mean().item():.4f}")
     checks = [r["encode"] < 2e-3, r["latents"] < 5e-3,
               r["decoded"] < 1.2e-3,                   # north_star's 1e-3 rel-L2 on the relit frames out of the denoise + decode path (measured 9.9e-4)
-              r["final_same_decoded"] < 5e-3,          # stage 1/2 from identical inputs (Adam(eps 1e-15) noise rows)
-              r["final"] < 3 * max(r["oracle_conditioning"], 3e-3)]       # whole path: within the algorithm's own sensitivity to the 1e-3 upstream
+              # after the two optimiser stages no pointwise 1e-3 exists for anyone: the engine must sit within the oracle's own self-distance
+              # (x1.5), from the same decoded frames and over the whole path; the per-iteration LOSSES must agree (checked below, 2e-2 per
+              # iteration -- measured 1e-5 at the last one)
+              r["final_same_decoded"] < 1.5 * max(r["oracle_vs_oracle_1e7"], 2e-3),
+              r["final"] < 1.5 * max(r["oracle_vs_oracle_1e7"], 2e-3)]
     loss_ok = np.allclose(l1h, np.asarray(l1), rtol=2e-2) and np.allclose(l2h, np.asarray(l2), rtol=2e-2)
 
     # ------------------------------------------------------------------ the oracle deciding its own matches

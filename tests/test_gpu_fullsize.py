@@ -282,15 +282,15 @@ def test_config5_stage2_full_size_properties():
     batch = np.array([[17, 250, 3, 120, 299, 64, 180, 1, 33, 90, 210, 5, 270, 150, 44, 0]], np.int32)
     _, feat1, l1 = P.unique_tensor_optimization(ds, inv, batch, batch_size=16, k=k)
     feat1 = feat1.t().contiguous()
-    moved = ((feat1 - feat0).abs() > 0).any(0)
+    lr = 0.05 * 16 / n
+    moved = ((feat1 - feat0).abs() > 0.25 * lr).any(0)          # (the scatter-mean initialisation sums with float atomics: two runs differ by ~1e-7)
     frames_touched = sorted({int(f) for f in batch[0]} | {max(int(f) - 1, 0) for f in batch[0]})
     touched = torch.zeros(k, dtype=torch.bool, device="cuda")
     for f in frames_touched:
         touched[inv[f * h * w:(f + 1) * h * w].long()] = True
     assert not (moved & ~touched).any()                                        # rows outside the batch's frames did not move
     assert moved.float().sum().item() > 0.5 * touched.float().sum().item()
-    lr = 0.05 * 16 / n
-    assert (feat1 - feat0).abs().max().item() <= lr * 1.0001
+    assert (feat1 - feat0).abs().max().item() <= lr * 1.001
     assert torch.isfinite(l1).all()
     # ---- iteration-level API == whole-stage driver
     from tc_light_amd.lib import stream

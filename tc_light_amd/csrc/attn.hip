@@ -91,8 +91,8 @@ __device__ __forceinline__ float xhalf_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB>
-__global__ __launch_bounds__(256, QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB>
+__global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
@@ -379,13 +379,13 @@ static void flash_prof_drain(bool all) {
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st) {
     constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -393,7 +393,7 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
         if (g_prof.ev.size() > 8192) flash_prof_drain(false);       // a 300-frame pass has ~1e5 launches: keep the live event count bounded
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -441,13 +441,16 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
                            d == 40 ? d : -1);
         hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV);
     }
-    // d = 40: two query blocks per wave (shared K/V fragments), 4-slot ring and two tiles per barrier (2 blocks per CU either way: +4.5%)
-    // when the grid still fills the chip several times over, else one block per wave, 3-slot ring, 3 blocks per CU (there the 4-slot
-    // ring would cost a block of occupancy: -6%; -20% for d = 80);
-    // d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
+    // d = 40: two query blocks per wave (shared K/V fragments), 4-slot ring and two tiles per barrier, 2 blocks per CU, when the grid still
+    // fills the chip several times over (750 TFLOP/s at T = 35.6k; the variants below reach 700 / 660 / 655 there); else one query block
+    // per wave on a 2-slot ring at 4 blocks per CU (107 VGPRs: four waves per SIMD hide each other's softmax; 582 vs 557 TFLOP/s at T = 8.9k
+    // for the 3-slot / 3-block variant).  d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
     const bool qb2 = (long)B * H * (Tqp / 256) >= 1024;
-    if (d == 40) return qb2 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
-                            : launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    static const int var40 = getenv("TCL_FLASH40") ? atoi(getenv("TCL_FLASH40")) : 0;      // tuning hook: force a d = 40 variant (tools/ab)
+    if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40 && var40 == 3) return launch_flash<40, 48, 64, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                                          : launch_flash<40, 48, 64, 1, 2, 1, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);

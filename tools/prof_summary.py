@@ -1,8 +1,10 @@
 """Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite output) as a text table.
-usage: prof_summary.py <dir> [rows] [--last-pass KERNEL]
+usage: prof_summary.py <dir> [rows] [--last-pass KERNEL | --timed-pass]
 --last-pass KERNEL: the traced command ran the workload twice (one warm-up pass that also carries the GEMM autotuner's timing
 launches, one timed pass); KERNEL is a kernel that closes a pass (stage 2's final k_gather_codebook): only kernels that start after
-the first half of its occurrences are summarised, i.e. the timed pass alone."""
+the first half of its occurrences are summarised, i.e. the timed pass alone.
+--timed-pass: bench.py of round 2 runs a truncated warm-up pass and ONE timed pass; each pass initialises stage 2 exactly once
+(k_scatter_final).  The timed pass starts after the last k_gather_codebook that precedes the second k_scatter_final."""
 import glob
 import re
 import sqlite3
@@ -17,6 +19,12 @@ if "--last-pass" in sys.argv:
     mark = sys.argv[sys.argv.index("--last-pass") + 1]
     ends = [r[0] for r in c.execute("select end from kernels where name like ? order by start", (f"%{mark}%",))]
     t0 = ends[len(ends) // 2 - 1]
+if "--timed-pass" in sys.argv:
+    sf = [r[0] for r in c.execute("select start from kernels where name like '%k_scatter_final%' order by start")]
+    if len(sf) >= 2:
+        t0 = c.execute("select max(end) from kernels where name like '%k_gather_codebook%' and start < ?", (sf[-1],)).fetchone()[0] or 0
+        w = c.execute("select min(start), max(end) from kernels where start > ?", (t0,)).fetchone()
+        print(f"# timed pass only: {(w[1] - w[0]) / 1e9:.2f} s between its first and last kernel")
 rows = c.execute("select name, count(*), sum(duration)/1e3, avg(duration)/1e3 from kernels where start > ? group by name order by 3 desc", (t0,)).fetchall()
 tot = sum(r[2] for r in rows)
 

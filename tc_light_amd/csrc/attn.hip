@@ -20,6 +20,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -102,6 +103,15 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     constexpr bool LROW = DPV > D;
     constexpr bool FOLD = DP > D && LROW && (D % 16 == 8);        // spare Q/K column D: lanes hl == 1, element 0 of fragment D/16
     constexpr bool PVQ = QB > 1;                                  // PV per query block right behind its softmax (V^T fragments held in registers)
+    // PV16 (head_dim 40): O^T = V^T.P^T on 16x16x32 MFMAs over 48 V^T rows (40 + the ones row + 7 idle) instead of 32x32x16 over 64: 12
+    // MFMAs of 16 cycles per query block and tile instead of 8 of 32 (-25 % PV matrix time).  The 32x32 S^T accumulator leaves lane l with
+    // query l & 31; a 16x16x32 B operand wants query l & 15 in all four 16-lane rows, the rows being four 8-key groups.  One
+    // v_permlane16_swap per register pair (first-8-keys register X, second-8-keys register Y of a 32-key block) does exactly that exchange:
+    // X.row1 <-> Y.row0, X.row3 <-> Y.row2 turns X into the operand of queries 0-15 and Y into that of queries 16-31, key groups in the order
+    // (A, B, C, D) = keys {0-3,8-11}, {16-19,24-27}, {4-7,12-15}, {20-23,28-31} -- which the V^T panel's in-tile key permutation already
+    // stores at halves 0, 16, 8, 24 of a 32-key block.
+    constexpr bool PV16 = D == 40 && LROW && DPV >= 48;
+    constexpr int NT16 = 3;                                       // 16-row V^T tiles: rows 0-39 V, row 40 ones, 41-47 zero
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
 
     const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
@@ -143,15 +153,20 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
         }                                                                                                                     \
     }
 
-    float16v o[QB][NDT];
+    float16v o[QB][PV16 ? 1 : NDT];
+    float4v o16[QB][2][PV16 ? NT16 : 1];          // PV16: [query block][queries 0-15 | 16-31][16-row tile]; lane l: rows 4 (l >> 4) + r, query l & 15
     float m[QB], lsum[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         m[qb] = FOLD ? 0.f : -1e30f; lsum[qb] = 0.f;
 #pragma unroll
-        for (int t = 0; t < NDT; ++t)
+        for (int t = 0; t < (PV16 ? 1 : NDT); ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][t][r] = 0.f;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int t = 0; t < (PV16 ? NT16 : 1); ++t) o16[qb][qt][t] = float4v{0.f, 0.f, 0.f, 0.f};
     }
 
     // MK = std::true_type: the tile may hold padded keys (only the last one does).  A compile-time switch, not `if (it >= nfull)`: hipcc turns
@@ -166,8 +181,15 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
 #pragma unroll
             for (int ks = 0; ks < NQK; ++ks) kf[blk][ks] = *(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16);
         half8 pf[QB][2][2];
-        half8 vfr[PVQ ? 2 : 1][2][NDT];               // PVQ: every V^T fragment of the tile in registers (read once, early)
-        if constexpr (PVQ) {
+        half8 vfr[PVQ && !PV16 ? 2 : 1][2][NDT];     // PVQ: every V^T fragment of the tile in registers (read once, early)
+        half8 vf16[PV16 ? 2 : 1][NT16];               // PV16: row t 16 + (l & 15), the 8 keys of group l >> 4 of 32-key block blk
+        if constexpr (PV16) {
+            const int goff = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) vf16[blk][t] = *(const half8*)(vt + (t * 16 + (lane & 15)) * V_STRIDE + blk * 32 + goff);
+        } else if constexpr (PVQ) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -226,10 +248,19 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                         const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
                         m[qb] = mn;
                         if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);        // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
+                        if constexpr (PV16) {
 #pragma unroll
-                        for (int t = 0; t < NDT; ++t)
+                            for (int qt = 0; qt < 2; ++qt) {
+                                const float aq = __shfl(alpha, (lane & 15) + 16 * qt, 64);      // this accumulator's query sits in another lane of the S^T layout
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+                                for (int t = 0; t < NT16; ++t) o16[qb][qt][t] *= aq;
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;
+                        }
 #pragma unroll
                         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -262,7 +293,23 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                     for (int r = 0; r < 16; ++r) { float p = __builtin_amdgcn_exp2f(s[blk][r] - m[qb]); if (!LROW) ps += p; pf[qb][blk][r >> 3][r & 7] = (_Float16)p; }
             }
             if (!LROW) lsum[qb] += ps;
-            if constexpr (PVQ) {
+            if constexpr (PV16) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    u32x4 x = __builtin_bit_cast(u32x4, pf[qb][blk][0]), y = __builtin_bit_cast(u32x4, pf[qb][blk][1]);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                        x[w] = sw[0]; y[w] = sw[1];
+                    }
+                    const half8 p0 = __builtin_bit_cast(half8, x), p1 = __builtin_bit_cast(half8, y);      // queries 0-15 | 16-31
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) {
+                        o16[qb][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p0, o16[qb][0][t], 0, 0, 0);
+                        o16[qb][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p1, o16[qb][1][t], 0, 0, 0);
+                    }
+                }
+            } else if constexpr (PVQ) {
                 // this query block's PV right behind its softmax: the 4 * NDT MFMAs run while the NEXT block's exponentials issue on the
                 // vector pipe (one wave then overlaps its own matrix and vector work instead of leaving that to its SIMD partner)
 #pragma unroll
@@ -273,7 +320,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                         for (int t = 0; t < NDT; ++t) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[blk][ss][t], pf[qb][blk][ss], o[qb][t], 0, 0, 0);
             }
         }
-        if constexpr (!PVQ) {
+        if constexpr (!PVQ && !PV16) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -334,6 +381,28 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     // ---- epilogue
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+        if constexpr (PV16) {
+            // O^T row 40 (the ones row: softmax row sums) = tile 2, lanes 32-47, register 0; lane l holds rows 16 t + 4 (l >> 4) + r of query
+            // (l & 15) + 16 qt: four consecutive output channels -> one 8-byte store per (qt, t)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float inv = 1.f / __shfl(o16[qb][qt][2][0], 32 + (lane & 15), 64);
+                const int q = q0 + qb * 32 + qt * 16 + (lane & 15);
+                if (q < Tq) {
+                    _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) {
+                        const int dd = t * 16 + 4 * (lane >> 4);
+                        if (dd < d) {
+                            const float4v v = o16[qb][qt][t];
+                            half4 w = {(_Float16)(v[0] * inv), (_Float16)(v[1] * inv), (_Float16)(v[2] * inv), (_Float16)(v[3] * inv)};
+                            *(half4*)(orow + dd) = w;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         float l;
         if (LROW) {      // l sits in O^T row D: tile D/32, register group (D%32)/8 (D%8 == 0), lanes with hl == (D%8)/4 == 0
             constexpr int TL = D / 32, RG = (D % 32) / 8;

@@ -1,7 +1,7 @@
 """GPU parity of the UNet engine (HIP, f16) against the fp32 CPU oracle on identical seeded weights and inputs.
 
 Stage (i)  -- VidToMe indices injected from the HIP run into the oracle: pure numeric parity of ~700 chained kernels.
-              Tolerance: rel-L2 <= 1e-2 on eps (f16 activations/weights vs f32 oracle; measured ~2-4e-3).
+              Tolerance: rel-L2 <= 3.5e-3 on eps (f16 activations/weights vs f32 oracle; measured 1.6e-3).
 Stage (ii) -- oracle computes its own matching with the f16-emulating rule: report map agreement and rel-L2.
 The oracle's UNet arithmetic itself is parity-UNPINNED w.r.t. diffusers (see oracle/sd15.py header).
 """
@@ -86,7 +86,7 @@ def test_unet_two_chunks(setup):
         ref = OS.unet_forward(sd, torch.cat([xs[k], xs[k]]), t, text, tome_injected)
         r = rel(hip[k], ref)
         print(f"[unet parity, injected indices] chunk {k}: rel-L2 = {r:.3e}")
-        assert r < 1e-2, r
+        assert r < 3.5e-3, r                           # measured 1.6e-3 (f16 activations through ~700 kernels vs the f32 oracle); 2x margin
         if k == 0:   # banks for chunk 1 in the oracle = unmerged local tokens; with no bank yet that is `local`
             pass
     # ---- stage (ii): oracle's own matching (f16-emulating tie rule), chunk 0 only (no bank dependence)
@@ -106,7 +106,7 @@ def test_unet_two_chunks(setup):
     print(f"[unet parity, computed indices] unmerge-map agreement per block: {['%.3f' % a for a in agree]}; rel-L2 = {r:.3e}")
     # random-weight activations are close to isotropic noise, so many cosine scores sit within one f16 ulp of each other and
     # the 1e-3-level activation differences flip some matches; the maps still mostly agree and the output stays close.
-    assert min(agree) > 0.6 and r < 1e-1
+    assert min(agree) > 0.7 and r < 3e-2           # measured: 82-97 % of the map entries per block, eps rel-L2 1.5e-2; ~2x margin
 
 
 def test_forward_many_equals_sequential(setup):
@@ -156,7 +156,7 @@ def test_forward_many_equals_sequential(setup):
     base, got = compare(seq1, seq2), compare(seq1, many)
     print("sequential vs sequential (min/mean map agreement, max eps rel-L2):", base, " sequential vs forward_many:", got)
     assert base == (1.0, 1.0, 0.0)                # deterministic kernels: no float atomics on the UNet path
-    assert got[1] > 0.85 and got[2] < 2e-2
+    assert got[1] > 0.86 and got[2] < 1.8e-2       # measured 0.91 / 0.009 (2x on the error, 1.5x on the disagreement)
 
 
 @pytest.mark.parametrize("Hh,Ww,Fs,Lt", [(4, 8, [2, 4, 2], 77), (5, 9, [3], 77), (9, 5, [3], 154), (6, 10, [1, 2], 77)])

@@ -185,6 +185,11 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
 size_t tcl_tome_match_workspace_bytes(int na);
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st);
+/* The same with a hint: the positions are affine -- a_pos[i] = i < a_split ? i : i + a_gap and b_pos[j] = b0 + j -- which is what every VidToMe
+ * match is (the dst frame of a random-frame merge, the two halves of a two-set merge).  For C = 320 this takes a kernel that keeps a src
+ * strip in registers and sweeps the dst tiles with a running maximum (csrc/merge.hip, k_tome_match320); same outputs, bit for bit. */
+int tcl_tome_match_affine_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                              int a_split, int a_gap, int b0, int* mrg, int* unm, void* ws, hipStream_t st);
 /* out[i] = outer[off + inner[i]] (inner NULL = identity): composition of unmerge maps (func_warper, vidtome/utils.py:42-48). */
 int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st);
 /* out[b][p] = map[p] >= 0 ? s1[b][map[p]] : s2[b][~map[p]]  (merge in "replace" mode; map NULL = copy). */

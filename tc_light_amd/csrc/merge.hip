@@ -8,6 +8,7 @@
 // Tie rule (the reference's is unspecified on GPU): highest score, then lowest concatenated dst index; equal scores
 // keep ascending src order.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/tclight_hip.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -180,6 +181,131 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 #undef TOME_ISSUE
 }
 
+// ---- C = 320 (level 0: 9/10 of the matching work), src / dst positions affine in the token sequence (every match VidToMe issues: the dst
+// frame of a random-frame merge and the src / dst halves of a two-set merge are contiguous runs).
+// Same keys as k_tome_match, bit for bit (same MFMA, same K order), different decomposition: the SRC strip is the block's own -- wave w
+// keeps the B operand of its 32 src columns in registers for all of K (20 half8 = 80 VGPRs) -- and the block sweeps the dst tiles of its
+// range, so the reduction over dst (the expensive part: ~4 vector instructions per score in k_tome_match's tile epilogue, as many
+// issue cycles as the tile's MFMAs) becomes a RUNNING packed-f16 maximum in registers: per 32-row MFMA tile 8 cvt_pk + 8 pk_max, and
+// the index scan (v_cmp + v_cndmask per element) runs only when some lane's running maximum actually grew -- record-breaking events,
+// ~ln(tiles) per column.  No per-tile atomics: one atomicMax per src row and dst split at the end.  LDS holds only dst rows: 64-wide K
+// stages (128 B per row, 16 KiB per stage, 3-slot ring), 16 MFMAs per wave and barrier instead of 8; rows are gathered by arithmetic
+// (no index loads in the loop, so the counted vmcnt only ever sees the LDS-DMA).  XCD x sweeps dst split x % nsplit: its L2 holds one range.
+// LDS image of a stage: row R at R * 128, its 16-B chunk g stored at position g ^ ((R >> 1) & 7): the 16-lane groups of a ds_read_b128
+// (MI355X_MICROARCH.md, LDS table) then touch 16 distinct slots of the 256-B bank window.
+__global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
+                                                          int b0, int nb, int tiles_dst, int nsplit, unsigned long long* __restrict__ keys) {
+    constexpr int C = 320, NST = C / 64, STAGE = 128 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
+    const int bid = blockIdx.x, x = bid & 7, per = 8 / nsplit;
+    const int split = x & (nsplit - 1), strip = (bid >> 3) * per + x / nsplit;
+    const int tps = (tiles_dst + nsplit - 1) / nsplit, t0 = split * tps, t1 = min(t0 + tps, tiles_dst);
+    if (strip * 128 >= na || t0 >= t1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, col = lane & 31;
+    const _Float16* zero = (const _Float16*)g_tome_zero;
+    // DMA roles: wave w stages pieces 4w .. 4w+3 (8 rows x 128 B each); lane -> row rr of the piece, LDS chunk position ch
+    const int rr = lane >> 3, ch = lane & 7;
+    const int si = strip * 128 + wid * 32 + col;                                   // this lane's src column
+    const long srow = si < na ? (long)(si < a_split ? si : si + a_gap) * C : -1;
+    const int ntl = t1 - t0, nstep = ntl * NST;
+    half2v pm = {(_Float16)(-65504.f), (_Float16)(-65504.f)};                       // running maxima of the lane's even / odd accumulator elements
+    int bi0 = 0x7fffffff, bi1 = 0x7fffffff;                                         // concatenated dst index where each was first attained
+    for (int bb = 0; bb < Bt; ++bb) {
+        const _Float16* base = metric + (long)bb * bstride;
+        half8 bfr[C / 16];                                                          // B operand: src column, k = 16 ks + 8 hl .. + 7
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) {
+            if (srow >= 0) bfr[ks] = *(const half8*)(base + srow + ks * 16 + 8 * hl);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfr[ks][j] = (_Float16)0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the fragment loads are the only non-DMA VMEM reads: drain before counting
+        int i_t = 0, i_k = 0;                                                       // (tile, stage) of the step being ISSUED
+#define T320_ISSUE(BUF)                                                                                                       \
+        {                                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+                const int piece = wid * 4 + i, R = piece * 8 + rr, dj = (t0 + i_t) * 128 + R;                                \
+                const _Float16* src_ = dj < nb ? base + (long)(b0 + dj) * C + i_k * 64 + ((ch ^ ((R >> 1) & 7)) << 3) : zero; \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                         \
+                                                 (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + piece * 1024), 16, 0, 0); \
+            }                                                                                                                 \
+            if (++i_k == NST) { i_k = 0; ++i_t; }                                                                             \
+        }
+        T320_ISSUE(0);
+        if (nstep > 1) T320_ISSUE(1);
+        int buf = 0, step = 0;
+        for (int tl = 0; tl < ntl; ++tl) {
+            float16v acc[4];
+#pragma unroll
+            for (int kt = 0; kt < NST; ++kt, ++step) {
+                if (step + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // my 4 pieces of this step landed; the next 4 stay in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (step + 2 < nstep) { const int nb_ = buf == 0 ? 2 : buf - 1; T320_ISSUE(nb_); }
+                const char* db = smem + buf * STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    half8 fa[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[a] = *(const half8*)(db + R * 128 + (((2 * ks + hl) ^ ((R >> 1) & 7)) << 4)); }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (kt == 0 && ks == 0) {
+                            float16v z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], bfr[0], z, 0, 0, 0);
+                        } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
+                    }
+                }
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+            // ---- score tile (128 dst x 32 src per wave) -> running maxima
+            const int dj0 = (t0 + tl) * 128, cat0 = bb * nb + dj0 + 4 * hl;
+            const bool tail = dj0 + 128 > nb;                                       // wave-uniform: rows past nb were fed zeros
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                half2v hp[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hp[q] = half2v{(_Float16)acc[a][2 * q], (_Float16)acc[a][2 * q + 1]};
+                if (tail) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int d0 = dj0 + a * 32 + 4 * hl + ((2 * q) & 3) + 8 * ((2 * q) >> 2);
+                        if (d0 >= nb) hp[q][0] = (_Float16)(-65504.f);
+                        if (d0 + 1 >= nb) hp[q][1] = (_Float16)(-65504.f);
+                    }
+                }
+                half2v tm = hp[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) tm = __builtin_elementwise_max(tm, hp[q]);
+                const half2v np = __builtin_elementwise_max(pm, tm);
+                const unsigned chg = __builtin_bit_cast(unsigned, np) ^ __builtin_bit_cast(unsigned, pm);
+                if (__any(chg != 0u)) {                                             // some lane's running maximum grew inside this 32-row tile
+                    asm volatile("; record");                                       // (a real branch: the scan below is the expensive part)
+                    int ilo = 0, ihi = 0;                                           // lowest element attaining the new maximum (descending scan)
+#pragma unroll
+                    for (int q = 7; q >= 0; --q) { ilo = hp[q][0] == np[0] ? q : ilo; ihi = hp[q][1] == np[1] ? q : ihi; }
+                    const int rl = 2 * ilo, rh = 2 * ihi + 1;
+                    if (chg & 0xFFFFu) bi0 = cat0 + a * 32 + (rl & 3) + 8 * (rl >> 2);
+                    if (chg >> 16) bi1 = cat0 + a * 32 + (rh & 3) + 8 * (rh >> 2);
+                }
+                pm = np;
+            }
+        }
+#undef T320_ISSUE
+        __builtin_amdgcn_s_barrier();                                               // everyone is done reading the ring before the next batch refills it
+    }
+    const _Float16 v = pm[0] > pm[1] ? pm[0] : pm[1];
+    const int idx = pm[0] > pm[1] ? bi0 : (pm[1] > pm[0] ? bi1 : min(bi0, bi1));
+    unsigned long long best = ((unsigned long long)sortable16(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+    const unsigned long long other = __shfl_xor(best, 32, 64);
+    best = other > best ? other : best;
+    if (hl == 0 && si < na) atomicMax(keys + si, best);
+}
+
 // Top-r selection and map construction without a sort (replaces key extraction + device radix sort + map building, ~8 launches per match,
 // by 3 small ones).  The r src tokens with the highest f16 score are merged, ties at the threshold go to the lowest src index
 // (= the order a stable descending sort would produce); the reference orders the remaining (unmerged) src slots by score as well, but
@@ -315,14 +441,26 @@ size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
 // Outputs: mrg int32 [na - r + nb], unm int32 [T'] (indexed by input position; every a_pos/b_pos entry is written).
-int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
-                       int* mrg, int* unm, void* ws, hipStream_t st) {
+static int tome_match_impl(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                           int* mrg, int* unm, void* ws, int affine, int a_split, int a_gap, int b0, hipStream_t st) {
     TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
     unsigned long long* keys = (unsigned long long*)ws;           // all-zero on entry (caller zeroes once; k_tome_select re-clears)
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
     const size_t lds = (size_t)3 * 256 * 64;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) {
+        (void)hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_tome_match320, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set = true;
+    }
+    static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
+    if (affine && C == 320 && use320) {
+        int nsplit = 1;
+        while (nsplit < 8 && (long)ts * nsplit < 768) nsplit *= 2;
+        while (nsplit > 1 && cdiv(td, nsplit) < 2) nsplit /= 2;
+        const int per = 8 / nsplit, groups = cdiv(ts, per);
+        hipLaunchKernelGGL(k_tome_match320, dim3(groups * 8), dim3(256), lds, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
+    } else {
     // each block keeps one dst tile and streams a run of src tiles; runs as long as possible while ~4 blocks per slot (256 CUs x 3) remain
     int spb = (int)((long)ts * td * Bt / 3072);
     if (spb < 1) spb = 1;
@@ -330,6 +468,7 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     const int nrange = cdiv(ts, spb);
     hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
                        spb, keys);
+    }
     int* aux = (int*)((char*)ws + ((size_t)na * 8 + 255) / 256 * 256);
     const int per = na <= 8 * 1024 ? 8 : (na <= 24 * 1024 ? 24 : 64);
     if (per == 8) hipLaunchKernelGGL(k_tome_thresh<8>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
@@ -338,6 +477,15 @@ int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const in
     const int nsb = cdiv(na, TOME_MAPS_BS);
     hipLaunchKernelGGL(k_tome_maps, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, aux, per, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();
+}
+int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                       int* mrg, int* unm, void* ws, hipStream_t st) {
+    return tome_match_impl(metric, bstride, Bt, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, 0, 0, 0, 0, st);
+}
+int tcl_tome_match_affine_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
+                              int a_split, int a_gap, int b0, int* mrg, int* unm, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(a_split >= 0 && a_gap >= 0 && b0 >= 0);
+    return tome_match_impl(metric, bstride, Bt, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, 1, a_split, a_gap, b0, st);
 }
 int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st) {
     TCL_CHECK_ARG(outer && out && n > 0);

@@ -83,8 +83,10 @@ class VidToMe:
             hit = self._pos[key] = torch.arange(lo, hi, dtype=I32, device=self.dev)
         return hit
 
-    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None):
-        """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps."""
+    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None):
+        """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps.
+        affine = (a_split, a_gap, b0): a_pos[i] = i if i < a_split else i + a_gap, b_pos[j] = b0 + j (true of every VidToMe match; lets the
+        C = 320 matches take the strip-resident kernel, csrc/merge.hip::k_tome_match320 -- same maps, bit for bit)."""
         L = self.L
         r = min(na, int(na * ratio))                                            # merge.py:90
         metric = torch.empty(2 * T, C, dtype=H16, device=self.dev)
@@ -99,7 +101,10 @@ class VidToMe:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)        # zeroed once; every match leaves it zero again
         mrg = torch.empty(na - r + nb, dtype=I32, device=self.dev)
         unm = torch.empty(T, dtype=I32, device=self.dev)
-        L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, self._ws, stream())
+        if affine is not None:
+            L.tcl_tome_match_affine_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mrg, unm, self._ws, stream())
+        else:
+            L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, self._ws, stream())
         return mrg, unm, na - r + nb
 
     # ---- patch.py:14-91
@@ -126,7 +131,8 @@ class VidToMe:
                                       f"({a['target_stride']}) frames (one randframe round) are implemented")
         if F > 1:
             a_pos, b_pos = self._positions(F, N, self.randf)
-            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=xbs)
+            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=xbs,
+                                         affine=(self.randf * N, N, self.randf * N))      # dst = the N tokens of frame randf, src = the rest
             local = torch.empty(2, TL, C, dtype=H16, device=self.dev)
             L.tcl_gather_rows_f16(x, xbs, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
         else:
@@ -155,7 +161,7 @@ class VidToMe:
         L.tcl_gather_rows_f16(local, TL * C, 0, 0, 0, cat[:, loff:], T * C, 2, TL, C, stream())
         L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, 2, Tb, C, stream())
         mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
-                                     a["global_merge_ratio"])
+                                     a["global_merge_ratio"], affine=(src_len, 0, src_len))
         merged = torch.empty(2, Tm, C, dtype=H16, device=self.dev)
         L.tcl_gather_rows_f16(cat, T * C, 0, 0, mrg2, merged, Tm * C, 2, Tm, C, stream())
         unm = torch.empty(F * N, dtype=I32, device=self.dev)

@@ -213,6 +213,50 @@ def test_unet_pass_full_size_deterministic(Hh, Ww, Fs, Lt):
     assert torch.equal(outs[0], outs[2])                 # the side-stream schedule changes timing only
 
 
+@pytest.mark.parametrize("N,F,randf,T2,src_len,ratio", [(14400, 4, 2, 0, 0, 0.6),        # config 3 local merge, dst frame in the middle (two src runs)
+                                                         (14400, 4, 0, 0, 0, 0.6),        # dst = first frame
+                                                         (5760, 3, 2, 0, 0, 0.9),         # yt plane of a 64-frame window, dst = last frame, ragged tiles
+                                                         (0, 0, 0, 63360, 31680, 0.5),    # config 3 two-set (global) merge, local tokens are src
+                                                         (0, 0, 0, 40777, 17017, 0.8),    # ragged sizes, config 4's global ratio
+                                                         (300, 4, 1, 0, 0, 0.6)])         # smaller than one dst split
+def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len, ratio):
+    """k_tome_match320 (src strip in registers, running maximum over the dst sweep; taken through tcl_tome_match_affine_f16 for C = 320)
+    must produce the SAME maps as the general tile-epilogue kernel (tcl_tome_match_f16), bit for bit: same MFMA, same K order, same key."""
+    C = 320
+    g = torch.Generator(device="cuda").manual_seed(N + T2 + randf)
+    if N:
+        T = F * N
+        idx = torch.arange(T, dtype=I32, device="cuda")
+        dst = (idx // N) % F == randf
+        a_pos, b_pos = idx[~dst].contiguous(), idx[dst].contiguous()
+        aff = (randf * N, N, randf * N)
+    else:
+        T = T2
+        a_pos, b_pos = torch.arange(0, src_len, dtype=I32, device="cuda"), torch.arange(src_len, T, dtype=I32, device="cuda")
+        aff = (src_len, 0, src_len)
+    na, nb = a_pos.numel(), b_pos.numel()
+    x = torch.randn(2, T, C, device="cuda", generator=g)
+    x[:, T // 3] = x[:, T // 2]                          # exact duplicates -> exact score ties: exercises the lowest-index rule
+    x[:, 5] = x[:, T - 7]
+    x = x.to(H)
+    metric = torch.empty_like(x)
+    L.tcl_tome_normalize_f16(x, metric, 2 * T, C, st())
+    r = min(na, int(na * ratio))
+    outs = []
+    for affine in (False, True):
+        ws = torch.zeros(L.tcl_tome_match_workspace_bytes(na), dtype=torch.uint8, device="cuda")
+        mrg = torch.full((na - r + nb,), -1, dtype=I32, device="cuda")
+        unm = torch.full((T,), -1, dtype=I32, device="cuda")
+        if affine:
+            L.tcl_tome_match_affine_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, aff[0], aff[1], aff[2], mrg, unm, ws, st())
+        else:
+            L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, st())
+        torch.cuda.synchronize()
+        assert not ws[: na * 8].any()
+        outs.append((mrg, unm))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_config3_windows_and_shards():
     """BASELINE config 3 host logic at size: 300 frames, window 64 -> 5 windows starting [0, 59, 118, 177, 236] with overlaps [5, 5, 5, 5]
     (generate.py:246-260), frames sharded 38/38/38/38/37/37/37/37, and the per-rank deal of the 5 x 40 yt items covers every

@@ -134,7 +134,7 @@ class ComputedToMe:
         return tome
 
 
-def oracle_denoise(sd_unet, x0, cc, text, text_t, cfg, tome, zs, xy_seed, yt_seed, on_step=None):
+def oracle_denoise(sd_unet, x0, cc, text, text_t, cfg, tome, zs, xy_seed, yt_seed, on_step=None, max_steps=None):
     """Generator.ddim_sample (generate.py:208-239) on the oracle: x0, cc [N,4,h,w] f32; cfg: the Generator's config namespace."""
     from tc_light_amd import hostlogic as HL            # the chunk draws: integer host logic pinned by tests/test_hostlogic_cpu.py
     c = cfg
@@ -150,6 +150,8 @@ def oracle_denoise(sd_unet, x0, cc, text, text_t, cfg, tome, zs, xy_seed, yt_see
         return OP.cfg(OS.unet_forward(sd_unet, torch.cat([xin, xin]), t, txt, tome.hook(size)), c.guidance_scale)
 
     for i, t in enumerate(osch.timesteps.tolist()):
+        if max_steps is not None and i >= max_steps:
+            break
         noises = torch.zeros_like(x)
         for ch in xy_s.get_chunks(n):
             noises[ch] = pred(torch.cat([x[ch], cc[ch]], 1), text, float(t), (h, w))

@@ -323,11 +323,17 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
     const float* img = cat + (size_t)j * 3 * P; const float* pre = cat + (size_t)(b + j) * 3 * P;
     float* gi = gcat + (size_t)j * 3 * P; float* gp = gcat + (size_t)(b + j) * 3 * P;
     const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
+    const int lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        int y = p / W, x = p - y * W;
-        Tap t = make_tap(fl[p], fl[P + p], x, y, W, H);
-        float m = mk[p], wv[3] = {0.f, 0.f, 0.f};
+    // every lane of a wave runs the same trip count (the shuffles below need all 64 lanes); lanes past the image are `live == false`
+    for (int p0 = blockIdx.x * blockDim.x; p0 < P; p0 += gridDim.x * blockDim.x) {
+        const int p = p0 + threadIdx.x;
+        const bool live = p < P;
+        const int pc = live ? p : P - 1;
+        const int y = pc / W, x = pc - y * W;
+        Tap t = make_tap(fl[pc], fl[P + pc], x, y, W, H);
+        const float m = live ? mk[pc] : 0.f;
+        float wv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
@@ -338,50 +344,47 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
                 wv[0] += wt * pre[a]; wv[1] += wt * pre[P + a]; wv[2] += wt * pre[2 * P + a];
             }
         }
-        float gw[3]; bool any = false;
+        float gw[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float d = wv[c] * m - img[c * P + p] * m;
+            float d = wv[c] * m - img[c * P + pc] * m;
             s += fabsf(d);
-            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * scale;
-            gi[c * P + p] -= gw[c];
-            any |= gw[c] != 0.f;
+            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * scale;      // 0 on dead lanes (m = 0)
+            if (live) gi[c * P + p] -= gw[c];
         }
-        // scatter of d(loss)/d(warped) into the pre-image gradient.  Fast path: when the 64 lanes of the wave are 64 consecutive
-        // pixels of one row whose taps share the same integer offset, lane l's tap i and lane l-i's tap 0.. land on the same
-        // cell, so the four column taps are merged across lanes with shuffles and ONE atomic per (row, channel) per lane is
-        // issued (12 instead of 48); the last three lanes emit the cells that stick out of the wave.
-        const int lane = threadIdx.x & 63, dx = t.x0 - x, dy = t.y0 - y;
-        const bool uni = __all(p + (63 - lane) < P && y == __builtin_amdgcn_readfirstlane(y) && dx == __builtin_amdgcn_readfirstlane(dx) &&
-                               dy == __builtin_amdgcn_readfirstlane(dy));
-        if (uni) {
-            for (int jj = 0; jj < 4; ++jj) {
-                const int yy = t.y0 + jj;
-                const bool rowok = yy >= 0 && yy < H;        // wave-uniform
+        // Scatter of d(loss)/d(warped) into the pre-image gradient: 16 taps x 3 channels per pixel.  Neighbouring pixels of a row whose taps
+        // share the integer offset (dx, dy) hit neighbouring cells: lane l's tap i and lane l+i's tap 0 are the SAME cell, so the four
+        // column taps are merged across lanes with shuffles and one atomic per (row, channel) is issued by the lane whose tap 0 owns the
+        // cell (12 atomics per pixel instead of 48).  The merge is SEGMENTED by the class (y, dx, dy): a lane only absorbs taps of the
+        // lanes of its own class and emits itself the taps no successor of its class absorbs -- so a wave that straddles an integer crossing
+        // of a smooth flow field, a row end or the image end still takes this path (an earlier all-or-nothing version fell back to 48
+        // atomics per pixel for the whole wave at every such crossing: 12x slower on flows that hover around an integer).
+        const int dx = t.x0 - x, dy = t.y0 - y;
+        const int ca = live ? ((dx << 16) | (dy & 0xffff)) : (int)0x80000000, cb = live ? y : -1 - lane;
+        bool up[4], dn[4];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float gwc = t.wy[jj] * gw[c];
-                    float v0 = gwc * t.wx[0], v1 = gwc * t.wx[1], v2 = gwc * t.wx[2], v3 = gwc * t.wx[3];
-                    float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
-                    float sum = v0 + (lane >= 1 ? u1 : 0.f) + (lane >= 2 ? u2 : 0.f) + (lane >= 3 ? u3 : 0.f);
-                    if (!rowok) continue;
-                    float* row = gp + (size_t)c * P + (size_t)yy * W;
-                    if (t.x0 >= 0 && t.x0 < W && sum != 0.f) atomicAdd(row + t.x0, sum);
-                    if (lane >= 61) {                        // taps that stick out of the wave: emitted by their own lane
-                        if (lane + 1 > 63 && t.x0 + 1 >= 0 && t.x0 + 1 < W) atomicAdd(row + t.x0 + 1, v1);
-                        if (lane + 2 > 63 && t.x0 + 2 >= 0 && t.x0 + 2 < W) atomicAdd(row + t.x0 + 2, v2);
-                        if (lane + 3 > 63 && t.x0 + 3 >= 0 && t.x0 + 3 < W) atomicAdd(row + t.x0 + 3, v3);
-                    }
-                }
-            }
-        } else if (any) {
-            for (int jj = 0; jj < 4; ++jj) {
-                int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
-                for (int i = 0; i < 4; ++i) {
-                    int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
-                    float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
-                    atomicAdd(gp + a, wt * gw[0]); atomicAdd(gp + P + a, wt * gw[1]); atomicAdd(gp + 2 * P + a, wt * gw[2]);
-                }
+        for (int i = 1; i < 4; ++i) {
+            // (all four shuffles unconditionally, combined with '&': a short-circuit '&&' would run them under a partial exec mask)
+            const int ua = __shfl_up(ca, i, 64), ub = __shfl_up(cb, i, 64), da = __shfl_down(ca, i, 64), db = __shfl_down(cb, i, 64);
+            up[i] = (lane >= i) & (ua == ca) & (ub == cb);          // lane l-i is of my class: I absorb its tap i
+            dn[i] = (lane + i <= 63) & (da == ca) & (db == cb);     // lane l+i is of my class: it absorbs my tap i
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int yy = t.y0 + jj;
+            const bool rowok = live && yy >= 0 && yy < H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gwc = t.wy[jj] * gw[c];
+                const float v0 = gwc * t.wx[0], v1 = gwc * t.wx[1], v2 = gwc * t.wx[2], v3 = gwc * t.wx[3];
+                const float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
+                const float sum = v0 + (up[1] ? u1 : 0.f) + (up[2] ? u2 : 0.f) + (up[3] ? u3 : 0.f);
+                if (!rowok) continue;
+                float* row = gp + (size_t)c * P + (size_t)yy * W;
+                if (t.x0 >= 0 && t.x0 < W && sum != 0.f) atomicAdd(row + t.x0, sum);
+                if (!dn[1] && v1 != 0.f && t.x0 + 1 >= 0 && t.x0 + 1 < W) atomicAdd(row + t.x0 + 1, v1);
+                if (!dn[2] && v2 != 0.f && t.x0 + 2 >= 0 && t.x0 + 2 < W) atomicAdd(row + t.x0 + 2, v2);
+                if (!dn[3] && v3 != 0.f && t.x0 + 3 >= 0 && t.x0 + 3 < W) atomicAdd(row + t.x0 + 3, v3);
             }
         }
     }

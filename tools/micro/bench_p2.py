@@ -8,7 +8,10 @@ g = torch.Generator(device="cuda").manual_seed(1)
 base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, h + 8, w + n + 8, device="cuda", generator=g), 9, stride=1, padding=4)
 ed = torch.stack([base[0, :, 4:4 + h, i:i + w] for i in range(n)]).contiguous()
 ed = (ed * (1 + 0.03 * torch.randn(n, 3, 1, 1, device="cuda", generator=g)) + 0.01 * torch.randn(ed.shape, device="cuda", generator=g)).clamp_(0, 1)
-flows = torch.zeros(n, 2, h, w, device="cuda"); flows[1:, 0] = 1.0; flows += 0.05 * torch.randn(flows.shape, device="cuda", generator=g); flows[0] = 0
+# a smooth, spatially varying flow field (a few px, integer crossings every ~100 px like camera / object motion) + estimator noise
+yy, xx = torch.meshgrid(torch.arange(h, device="cuda", dtype=torch.float32), torch.arange(w, device="cuda", dtype=torch.float32), indexing="ij")
+flows = torch.stack([1.3 + 1.5 * torch.sin(xx / 160 + yy / 300), 0.4 + 1.0 * torch.cos(yy / 120 - xx / 400)])[None].repeat(n, 1, 1, 1)
+flows = flows * (1 + 0.1 * torch.randn(n, 1, 1, 1, device="cuda", generator=g)) + 0.02 * torch.randn(flows.shape, device="cuda", generator=g); flows[0] = 0
 masks = (torch.rand(n, 1, h, w, device="cuda", generator=g) > 0.1).float()
 ids = torch.empty(n, h, w, dtype=torch.int64, device="cuda"); ids[0] = torch.arange(h * w, device="cuda").view(h, w); last = h * w
 for k in range(1, n):

@@ -319,58 +319,95 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
 // their src index order here.  Maps of SURVEY 8(a) A12/A13:
 //  mrg[p]  (p in [0, na-r+nb))  = input position feeding merged slot p          (merge, mode "replace")
 //  unm[pos] (pos in input seq)  = merged slot that input position pos is restored from (unmerge)
-// pass 1 (one block): threshold score of the r-th largest element (bitwise radix select over register-cached scores) and, for
-// every chunk of PER consecutive src indices, the number of ties / lower scores before it (exclusive scans) -> aux
-template <int PER>
-__global__ __launch_bounds__(1024) void k_tome_thresh(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ aux) {
-    __shared__ int sc_a[1024], sc_b[1024];
-    const int tid = threadIdx.x, i0 = tid * PER;
-    unsigned short sv[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) sv[j] = i0 + j < na ? (unsigned short)((keys[i0 + j] >> 32) & 0xFFFFu) : (unsigned short)0;
-    int thr = 0x10000, take = 0;                     // r == 0: nothing merged
-    if (r > 0) {
-        // Radix select of the r-th largest 16-bit score, one bit per pass from the MSB, on the scores held in registers: count the
-        // candidates that match the decided prefix and have this bit set; if they cover what is still needed the threshold has the
-        // bit, else all of them lie above the threshold and are taken.  No atomics (cosine scores crowd into a few histogram bins:
-        // the LDS-atomic histogram this replaces serialised on them -- 218 us at 64k keys, now ~16), one barrier per pass: wave sums
-        // by ballot + popcount over the bits of the per-thread count, cross-wave through a double-buffered 16-entry LDS array.
-        const int lane = tid & 63, wv = tid >> 6;
-        int prefix = 0, need = r;
-        for (int bit = 15; bit >= 0; --bit) {
-            const unsigned cand = (unsigned)prefix | (1u << bit), mask = 0xFFFFu & ~((1u << bit) - 1u);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < PER; ++j) cnt += ((unsigned)sv[j] & mask) == cand;      // out-of-range slots hold 0 and never match (cand != 0)
-            int wsum = 0;
-#pragma unroll
-            for (int bq = 0; (1 << bq) <= PER; ++bq) wsum += __popcll(__ballot((cnt >> bq) & 1)) << bq;
-            int* buf = sc_a + (bit & 1) * 16;
-            if (lane == 0) buf[wv] = wsum;
-            __syncthreads();
-            int tot = 0;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) tot += buf[w];
-            if (tot >= need) prefix = (int)cand; else need -= tot;
-        }
-        thr = prefix; take = need;
-        __syncthreads();                                // sc_a is reused by the scans below
-    }
-    int n_tie = 0, n_low = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        if (i0 + j >= na) break;
-        n_tie += (int)sv[j] == thr; n_low += (int)sv[j] < thr;
-    }
-    sc_a[tid] = n_tie; sc_b[tid] = n_low;
+// pass 1: threshold score of the r-th largest element and, for every chunk of PER consecutive src indices, the number of ties / lower
+// scores before it (exclusive scans) -> aux.  Four SMALL launches (256-thread blocks, < 40 VGPRs, <= 8 KiB LDS) instead of one 1024-thread
+// block holding every score in registers: in the pipeline this chain runs on a side stream beside the flash kernel, whose two blocks per
+// CU hold 444 of a SIMD's 512 registers and 132 of the 160 KiB of LDS -- the big block could only start on a CU that BOTH flash blocks had left
+// (97 us alone, 1 150 us average in the profiled 300-frame pass: 5 % of all kernel time and on the matching chain's critical path); small
+// blocks slip into the register / LDS remainder of any CU.  Two-level radix select on the 16-bit scores: histogram of the high byte
+// (grid; LDS atomics on 256 bins per block, then one global add per bin), pick the bucket that holds the r-th largest (one block),
+// histogram of the low byte inside that bucket (grid), pick the threshold and run the chunk scans (one block, LDS counters + Hillis-Steele).
+// hist: 512 ints, all-zero on entry and left all-zero (the last kernel clears them), like the key array.
+#define THR_BS 256
+__global__ __launch_bounds__(THR_BS) void k_thr_hist(const unsigned long long* __restrict__ keys, int na, int level, const int* __restrict__ sel,
+                                                     int* __restrict__ hist) {
+    __shared__ int h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scans over the 1024 chunk totals
-        const int va = tid >= off ? sc_a[tid - off] : 0, vb = tid >= off ? sc_b[tid - off] : 0;
+    const int bucket = level ? sel[0] : 0;
+    for (int i = blockIdx.x * THR_BS + tid; i < na; i += gridDim.x * THR_BS) {
+        const unsigned sc = (unsigned)((keys[i] >> 32) & 0xFFFFu);
+        if (!level) atomicAdd(&h[sc >> 8], 1);
+        else if ((int)(sc >> 8) == bucket) atomicAdd(&h[sc & 255u], 1);
+    }
+    __syncthreads();
+    if (h[tid]) atomicAdd(hist + level * 256 + tid, h[tid]);
+}
+// suffix sums from the top bin: bucket b with count(bins > b) < need <= count(bins >= b); sel[0] = b, sel[1] = need - count(bins > b)
+__device__ __forceinline__ void thr_pick(const int* __restrict__ hist, int need, int* bucket, int* rest, int* sc /* LDS, 256 */) {
+    const int tid = threadIdx.x;
+    sc[tid] = hist[255 - tid];                          // descending bin order
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? sc[tid - off] : 0;
         __syncthreads();
-        sc_a[tid] += va; sc_b[tid] += vb;
+        sc[tid] += v;
         __syncthreads();
     }
-    aux[2 + 2 * tid] = sc_a[tid] - n_tie; aux[3 + 2 * tid] = sc_b[tid] - n_low;      // exclusive prefixes of chunk tid
+    const int incl = sc[tid], excl = incl - hist[255 - tid];
+    if (excl < need && need <= incl) { *bucket = 255 - tid; *rest = need - excl; }
+    __syncthreads();
+}
+__global__ __launch_bounds__(THR_BS) void k_thr_pick1(int* __restrict__ hist, int r, int* __restrict__ sel) {
+    __shared__ int sc[256];
+    __shared__ int b, rest;
+    if (threadIdx.x == 0) { b = 0; rest = 0; }
+    __syncthreads();
+    if (r > 0) thr_pick(hist, r, &b, &rest, sc);
+    __syncthreads();
+    if (threadIdx.x == 0) { sel[0] = b; sel[1] = rest; }
+    hist[threadIdx.x] = 0;                              // level-0 histogram consumed: leave it zero for the next match
+}
+template <int PER>
+__global__ __launch_bounds__(THR_BS) void k_thr_final(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ hist, const int* __restrict__ sel,
+                                                      int* __restrict__ aux) {
+    __shared__ int sc[256];
+    __shared__ int ctie[1024], clow[1024];
+    __shared__ int b2, take_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) { b2 = 0; take_s = 0; }
+    for (int c = tid; c < 1024; c += THR_BS) { ctie[c] = 0; clow[c] = 0; }
+    __syncthreads();
+    int thr = 0x10000, take = 0;                        // r == 0: nothing merged
+    if (r > 0) {
+        thr_pick(hist + 256, sel[1], &b2, &take_s, sc);
+        thr = (sel[0] << 8) | b2; take = take_s;
+    }
+    hist[256 + tid] = 0;
+    // per-chunk counts of ties / lower scores (chunk = PER consecutive src indices), then exclusive scans over the 1024 chunks
+    for (int i = tid; i < na; i += THR_BS) {
+        const int s16 = (int)((keys[i] >> 32) & 0xFFFFu);
+        if (s16 == thr) atomicAdd(&ctie[i / PER], 1);
+        else if (s16 < thr) atomicAdd(&clow[i / PER], 1);
+    }
+    __syncthreads();
+    // 4 consecutive chunks per thread: local exclusive prefix + block scan of the thread totals
+    int t4[4], l4[4], tt = 0, ll = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { t4[q] = tt; l4[q] = ll; tt += ctie[tid * 4 + q]; ll += clow[tid * 4 + q]; }
+    __syncthreads();
+    sc[tid] = tt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
+    const int tbase = sc[tid] - tt;
+    __syncthreads();
+    sc[tid] = ll;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
+    const int lbase = sc[tid] - ll;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { aux[2 + 2 * (tid * 4 + q)] = tbase + t4[q]; aux[3 + 2 * (tid * 4 + q)] = lbase + l4[q]; }
     if (tid == 0) { aux[0] = thr; aux[1] = take; }
 }
 // pass 2 (grid): maps, one thread per src / dst token.  Blocks of 192 threads (a multiple of every PER) own whole PER-chunks of src
@@ -442,7 +479,7 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
     TCL_LAUNCH_RET();
 }
 
-size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024) * 4 + 1024; }
+size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024 + 512 + 2) * 4 + 1024; }
 
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
@@ -477,9 +514,15 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     }
     int* aux = (int*)((char*)ws + ((size_t)na * 8 + 255) / 256 * 256);
     const int per = na <= 8 * 1024 ? 8 : (na <= 24 * 1024 ? 24 : 64);
-    if (per == 8) hipLaunchKernelGGL(k_tome_thresh<8>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
-    else if (per == 24) hipLaunchKernelGGL(k_tome_thresh<24>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
-    else hipLaunchKernelGGL(k_tome_thresh<64>, dim3(1), dim3(1024), 0, st, keys, na, r, aux);
+    int* hist = aux + 2 + 2 * 1024;                     // 512 bins (zero between calls) + 2 selector words
+    int* sel = hist + 512;
+    const int hg = na >= 16384 ? 64 : (na >= 2048 ? 16 : 2);
+    hipLaunchKernelGGL(k_thr_hist, dim3(hg), dim3(THR_BS), 0, st, keys, na, 0, sel, hist);
+    hipLaunchKernelGGL(k_thr_pick1, dim3(1), dim3(THR_BS), 0, st, hist, r, sel);
+    hipLaunchKernelGGL(k_thr_hist, dim3(hg), dim3(THR_BS), 0, st, keys, na, 1, sel, hist);
+    if (per == 8) hipLaunchKernelGGL(k_thr_final<8>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
+    else if (per == 24) hipLaunchKernelGGL(k_thr_final<24>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
+    else hipLaunchKernelGGL(k_thr_final<64>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
     const int nsb = cdiv(na, TOME_MAPS_BS);
     hipLaunchKernelGGL(k_tome_maps, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, aux, per, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();

@@ -479,7 +479,7 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
     TCL_LAUNCH_RET();
 }
 
-size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024 + 512 + 2) * 4 + 1024; }
+size_t tcl_tome_match_workspace_bytes(int na) { return 4096 + ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024) * 4 + 1024; }
 
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
@@ -487,7 +487,12 @@ size_t tcl_tome_match_workspace_bytes(int na) { return ((size_t)na * 8 + 255) / 
 static int tome_match_impl(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                            int* mrg, int* unm, void* ws, int affine, int a_split, int a_gap, int b0, hipStream_t st) {
     TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
-    unsigned long long* keys = (unsigned long long*)ws;           // all-zero on entry (caller zeroes once; k_tome_select re-clears)
+    // ws: [histograms 512 ints + 2 selector words | keys na x 8 B | aux]; histograms and keys are all-zero on entry (the caller zeroes the
+    // workspace once) and are left all-zero -- the histograms sit at a FIXED offset so that a workspace re-used for a different na never
+    // maps them onto a previous call's (non-zero) aux words
+    int* hist = (int*)ws;
+    int* sel = hist + 512;
+    unsigned long long* keys = (unsigned long long*)((char*)ws + 4096);
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
     const size_t lds = (size_t)3 * 256 * 64;
     static bool set = false;
@@ -512,10 +517,8 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
                        spb, keys);
     }
-    int* aux = (int*)((char*)ws + ((size_t)na * 8 + 255) / 256 * 256);
+    int* aux = (int*)((char*)ws + 4096 + ((size_t)na * 8 + 255) / 256 * 256);
     const int per = na <= 8 * 1024 ? 8 : (na <= 24 * 1024 ? 24 : 64);
-    int* hist = aux + 2 + 2 * 1024;                     // 512 bins (zero between calls) + 2 selector words
-    int* sel = hist + 512;
     const int hg = na >= 16384 ? 64 : (na >= 2048 ? 16 : 2);
     hipLaunchKernelGGL(k_thr_hist, dim3(hg), dim3(THR_BS), 0, st, keys, na, 0, sel, hist);
     hipLaunchKernelGGL(k_thr_pick1, dim3(1), dim3(THR_BS), 0, st, hist, r, sel);

@@ -116,7 +116,7 @@ def test_tome_match_full_size_invariants(L, na, nb, C, ratio):
     unm = torch.full((T,), -1, dtype=I32, device="cuda")
     L.tcl_tome_match_f16(metric, T * C, Bt, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, st())
     torch.cuda.synchronize()
-    assert not ws[: 4096 + na * 8].any()                # histograms + key array are left cleared for the next match (documented contract)
+    assert not ws[:2048].any() and not ws[4096: 4096 + na * 8].any()      # histograms + key array are left cleared for the next match (documented contract)
     nun = na - r
     u = unm[:na].long()
     merged = u >= nun
@@ -252,7 +252,7 @@ def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len,
         else:
             L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, st())
         torch.cuda.synchronize()
-        assert not ws[: 4096 + na * 8].any()
+        assert not ws[:2048].any() and not ws[4096: 4096 + na * 8].any()
         outs.append((mrg, unm))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 

@@ -51,8 +51,12 @@ __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int 
 // (p swaps bits 2 and 3 of t): the S^T accumulator of the flash kernel leaves lane half hl with keys {4hl..4hl+3, 8+4hl..8+4hl+3}
 // of a group, and with this order those 8 V^T values are one contiguous 16-B LDS read (8*hl .. 8*hl+7).  Row D (when DPV > D) is
 // a row of ones over the valid keys: the PV MFMA then also yields the softmax row sums.
+// skew (head_dim 40, whose PV runs on 16x16x32 MFMAs): rows 4..11 (mod 16) swap the two 16-key halves of every 32-key block (position ^ 16).
+// The 16x16x32 A fragment read has lane l fetch row l & 15 at key group l >> 4, and a ds_read_b128 lane group mixes rows 0-3 / 12-15 of one
+// key group with rows 4-11 of another: without the skew two pairs of lanes share a 16-B bank slot (SQ_LDS_BANK_CONFLICT = 1/3 of the kernel's
+// LDS cycles); with it all 16 slots of the 256-B bank window are distinct (exhaustive check of the four lane groups).
 __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
-                                                 _Float16* __restrict__ vt, int ntiles, int DPV) {
+                                                 _Float16* __restrict__ vt, int ntiles, int DPV, int skew) {
     extern __shared__ _Float16 tile[];   // [64][DPV+2]
     const int t0 = blockIdx.x * 64, bh = blockIdx.y, h = bh % H; const long b = bh / H;
     const int st = DPV + 2, cpr = DPV / 8;
@@ -71,7 +75,8 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
         int dd = i / 64, r = i % 64;
         _Float16 val = tile[r * st + dd];
         if (dd == d && DPV > d) val = (t0 + r < T) ? (_Float16)1.f : (_Float16)0.f;
-        const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+        if (skew && (((dd & 15) + 4) & 8)) pr ^= 16;
         out[dd * V_STRIDE + pr] = val;
     }
 }
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
         half8 vfr[PVQ && !PV16 ? 2 : 1][2][NDT];     // PVQ: every V^T fragment of the tile in registers (read once, early)
         half8 vf16[PV16 ? 2 : 1][NT16];               // PV16: row t 16 + (l & 15), the 8 keys of group l >> 4 of 32-key block blk
         if constexpr (PV16) {
-            const int goff = ((lane >> 4) & 1) * 16 + (lane >> 5) * 8;
+            const int goff = (((lane >> 4) & 1) * 16 + (lane >> 5) * 8) ^ ((((lane & 15) + 4) & 8) ? 16 : 0);      // (^ 16: the panel's row skew, k_pack_vt)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -429,6 +434,214 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Head_dim 40, software-pipelined across key tiles (k_flash40p).  The loop of k_flash is bound by VALU issue, and within one wave its
+// matrix and vector work are a dependency chain (QK^T -> max -> exp -> PV): the two pipes only overlap where the two waves of a SIMD
+// happen to be in opposite phases (matrix pipe 46 %, VALU 68 % busy).  Here every loop iteration i issues three INDEPENDENT streams:
+//     vector:  softmax of tile i          (scores from the QK^T MFMAs issued one iteration earlier)
+//     matrix:  PV of tile i-1             (P from the softmax of the previous iteration)
+//     matrix:  QK^T of tile i+1           (for the softmax of the next iteration)
+// so one wave keeps both pipes busy by itself.  The price is two score tiles and two P tiles live: with ONE 32-query block per wave that
+// is ~170 VGPRs (two query blocks would need ~300), i.e. each K / V^T fragment read from LDS feeds one MFMA instead of two -- LDS array
+// time doubles to ~28 %, still off the critical path.  Same arithmetic as k_flash<40,...> (swapped-operand S^T, shift folded into the
+// spare Q column, ones-row row sums, PV on 16x16x32 MFMAs, lazy re-basing when a row maximum climbs 2^6 above the shift).
+// Ring of 4 tile slots: iteration i reads V^T of tile i-1 and K of tile i+1 while tile i+2 streams in; one barrier per tile.
+// Re-basing at tile i (rare): PV(i-1) is issued early in that path (it belongs to the old shift), O and the scores of tile i move to the
+// new shift, and the QK^T of tile i+1 -- issued after the decision -- already sees the new shift in the Q column.
+template <int NW, int NSTG>        // waves per block (4: two blocks per CU; 8: one), ring slots (prefetch distance NSTG - 3 tiles beyond the next)
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_flash40p(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                                    _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int ldo, long obstride,
+                                                    int kv_div, int nqb) {
+    constexpr int D = 40, DP = 48, DPV = 64, KS = DP + 8, NQK = 3, NT16 = 3, PF = NSTG - 3;      // PF: tiles in flight beyond tile it+1
+    constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = DPV * V_STRIDE * 2, SBYTES = KBYTES + VBYTES, NPIECE = SBYTES / 1024, NPW = NPIECE / NW, SSTRIDE = SBYTES;
+    static_assert(KBYTES % 1024 == 0 && NPIECE % NW == 0 && PF >= 1 && PF <= 3, "tile image must split into NW x NPW pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
+    const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, ql = lane & 31;
+    const int q0 = qb_ * (NW * 32) + wid * 32;
+    const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
+    const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;
+    const char* kbase = (const char*)(Kp + kbh * Tkp * KS);
+    const char* vbase = (const char*)(Vt + kbh * nt * DPV * V_STRIDE);
+    const int lane16 = lane * 16, goff = (((lane >> 4) & 1) * 16 + (lane >> 5) * 8) ^ ((((lane & 15) + 4) & 8) ? 16 : 0);
+    half8 qf[NQK];
+    {
+        const _Float16* qrow = Qp + (bh * Tqp + q0 + ql) * DP + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NQK; ++ks) qf[ks] = *(const half8*)(qrow + ks * 16);
+    }
+#define P40_ISSUE(IT)                                                                                                         \
+    {                                                                                                                         \
+        const char* kt_ = kbase + (long)(IT) * KBYTES;                                                                        \
+        const char* vt_ = vbase + (long)(IT) * VBYTES;                                                                        \
+        const int st_ = ((IT) % NSTG) * SSTRIDE;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
+            const int pb_ = (wid + NW * i) * 1024;                                                                            \
+            const char* src_ = (pb_ < KBYTES ? kt_ + pb_ : vt_ + (pb_ - KBYTES)) + lane16;                                    \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
+                                             (__attribute__((address_space(3))) void*)(lds0 + st_ + pb_), 16, 0, 0);          \
+        }                                                                                                                     \
+    }
+    float4v o16[2][NT16];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) o16[qt][t] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m = 0.f;
+    // QK^T of one tile: S^T[key, query] for the wave's 32 queries against the 64 keys of the tile in ring slot (it & 3)
+    auto qk = [&](const int it, float16v (&sc)[2]) __attribute__((always_inline)) {
+        const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            half8 kf[NQK];
+#pragma unroll
+            for (int ks = 0; ks < NQK; ++ks) kf[ks] = *(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16);
+            float16v z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], z, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < NQK; ++ks) sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], sc[blk], 0, 0, 0);
+        }
+    };
+    // O^T += V^T . P^T of one tile (P already in the 16x16x32 operand layout: [blk][queries 0-15 | 16-31])
+    auto pv = [&](const int it, const half8 (&pp)[2][2]) __attribute__((always_inline)) {
+        const _Float16* vt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE + KBYTES);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                const half8 vf = *(const half8*)(vt + (t * 16 + (lane & 15)) * V_STRIDE + blk * 32 + goff);
+                o16[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pp[blk][0], o16[0][t], 0, 0, 0);
+                o16[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pp[blk][1], o16[1][t], 0, 0, 0);
+            }
+    };
+    // exp2 of one score tile -> P in the PV operand layout (cvt_pk pairs + permlane16 exchange, see k_flash PV16)
+    auto softmax = [&](const float16v (&sc)[2], half8 (&pp)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            half8 x, y;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { x[r] = (_Float16)__builtin_amdgcn_exp2f(sc[blk][r]); y[r] = (_Float16)__builtin_amdgcn_exp2f(sc[blk][8 + r]); }
+            u32x4 xu = __builtin_bit_cast(u32x4, x), yu = __builtin_bit_cast(u32x4, y);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+                xu[w] = sw[0]; yu[w] = sw[1];
+            }
+            pp[blk][0] = __builtin_bit_cast(half8, xu); pp[blk][1] = __builtin_bit_cast(half8, yu);
+        }
+    };
+    // One pipeline step for tile `it`: scores of tile it in sc, P of tile it-1 in pprev; leaves scores of it+1 in snext and P of it in pcur.
+    // FIRST: tile 0 (no pending PV, the shift is always based); LAST: no next tile.  The steady state (neither) has NO conditional around its
+    // three streams, so they are one basic block for the scheduler; the rare re-basing path carries its own copy of the streams.
+    auto step = [&](const int it, float16v (&sc)[2], float16v (&snext)[2], const half8 (&pprev)[2][2], half8 (&pcur)[2][2], auto FIRST, auto LAST)
+                    __attribute__((always_inline)) {
+        constexpr bool first = decltype(FIRST)::value, last = decltype(LAST)::value;
+        if (it >= nfull) {                                                      // wave-uniform: only the last tile has padded keys
+            asm volatile("; mask");
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) sc[blk][r] = -1e30f; }
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[blk][r]);
+        mx = xhalf_max(mx);
+        if (first || __any(mx > 6.f)) {                                         // re-base the shift (tile 0 always; later only on a 2^6 climb)
+            if (!first) { asm volatile("; rebase"); pv(it - 1, pprev); }        // the pending PV belongs to the OLD shift: add it before O is rescaled
+            const float mn = (float)(_Float16)(m + (first ? mx : fmaxf(mx, 0.f)));
+            const float delta = mn - m, alpha = __builtin_amdgcn_exp2f(-delta);
+            m = mn;
+            if (hl == 1) qf[D / 16][0] = (_Float16)(-mn);
+            if (!first) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const float aq = __shfl(alpha, (lane & 15) + 16 * qt, 64);
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) o16[qt][t] *= aq;
+                }
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[blk][r] -= delta;
+            if (!last) qk(it + 1, snext);
+            softmax(sc, pcur);
+        } else {
+            // the three independent streams of the steady state
+            pv(it - 1, pprev);
+            if (!last) qk(it + 1, snext);
+            softmax(sc, pcur);
+        }
+    };
+    // Before step `it`: tile it+1 (its K is read by this step's QK^T) must have landed -- up to PF younger tiles stay in flight (counted
+    // vmcnt); past the barrier every wave has finished step it-1, i.e. the V^T of tile it-2, so slot (it+1+PF) % NSTG is free for tile it+1+PF.
+#define P40_SYNC(IT)                                                                                                          \
+    if ((IT) + 1 < nt) {                                                                                                      \
+        /* in flight here: tiles IT+1 .. IT+PF (those that exist); tile IT+1 has landed once at most the younger ones remain */ \
+        if (PF >= 3 && (IT) + 3 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");                          \
+        else if (PF >= 2 && (IT) + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");                         \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                         \
+        if ((IT) + 1 + PF < nt) P40_ISSUE((IT) + 1 + PF);                                                                     \
+    }
+    float16v sA[2], sB[2];
+    half8 pA[2][2], pB[2][2];
+    const std::true_type T_{}; const std::false_type F_{};
+    P40_ISSUE(0);
+#pragma unroll
+    for (int j = 1; j <= PF; ++j) if (j < nt) P40_ISSUE(j);                     // tiles 1 .. PF in flight behind tile 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // (prologue: simply everything)
+    __builtin_amdgcn_s_barrier();                                               // tile 0 landed for every wave
+    qk(0, sA);
+    if (nt == 1) { step(0, sA, sB, pB, pA, T_, T_); pv(0, pA); }
+    else {
+        P40_SYNC(0);
+        step(0, sA, sB, pB, pA, T_, F_);                                        // -> P(0) in pA, scores(1) in sB
+        int it = 1;
+        for (; it + 2 < nt; it += 2) {                                          // it odd; steps it and it+1 are both steady
+            P40_SYNC(it);
+            step(it, sB, sA, pA, pB, F_, F_);
+            P40_SYNC(it + 1);
+            step(it + 1, sA, sB, pB, pA, F_, F_);
+        }
+        if (it + 1 < nt) {                                                      // two tiles left: a steady odd step, then the last (even) one
+            P40_SYNC(it);
+            step(it, sB, sA, pA, pB, F_, F_);
+            step(it + 1, sA, sB, pB, pA, F_, T_);
+            pv(it + 1, pA);
+        } else {                                                                // one tile left (odd)
+            step(it, sB, sA, pA, pB, F_, T_);
+            pv(it, pB);
+        }
+    }
+#undef P40_SYNC
+#undef P40_ISSUE
+    // ---- epilogue (as k_flash PV16): row sums in O^T row 40 = tile 2, lanes 32-47, register 0
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float inv = 1.f / __shfl(o16[qt][2][0], 32 + (lane & 15), 64);
+        const int q = q0 + qt * 16 + (lane & 15);
+        if (q < Tq) {
+            _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * D;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                const int dd = t * 16 + 4 * (lane >> 4);
+                if (dd < D) {
+                    const float4v v = o16[qt][t];
+                    half4 w = {(_Float16)(v[0] * inv), (_Float16)(v[1] * inv), (_Float16)(v[2] * inv), (_Float16)(v[3] * inv)};
+                    *(half4*)(orow + dd) = w;
+                }
+            }
+        }
+    }
+}
+
 // ---- optional in-library timing of the flash kernel (bench.py roofline leg): HIP events recorded on the launch stream
 #include <vector>
 #include <deque>
@@ -464,6 +677,24 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     }
     hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+static int launch_flash40p(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
+                           int ldo, long obs, int kv_div, hipStream_t st) {
+    constexpr int NW = 8, NSTG = 6;
+    const size_t lds = (size_t)NSTG * (KV_TILE * 56 * 2 + 64 * V_STRIDE * 2);
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash40p<NW, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / (NW * 32);
+    const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == 40);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+        if (g_prof.ev.size() > 8192) flash_prof_drain(false);
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
+    }
+    hipLaunchKernelGGL((k_flash40p<NW, NSTG>), dim3(B * H * nqb), dim3(NW * 64), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, nqb);
+    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * 40; g_prof.launches++; }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -508,7 +739,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (pack_kv) {
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, KS, kc,
                            d == 40 ? d : -1);
-        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV);
+        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV, d == 40 ? 1 : 0);
     }
     // d = 40: two query blocks per wave (shared K/V fragments), 4-slot ring and two tiles per barrier, 2 blocks per CU, when the grid still
     // fills the chip several times over (750 TFLOP/s at T = 35.6k; the variants below reach 700 / 660 / 655 there); else one query block
@@ -516,6 +747,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     // for the 3-slot / 3-block variant).  d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
     const bool qb2 = (long)B * H * (Tqp / 256) >= 1024;
     static const int var40 = getenv("TCL_FLASH40") ? atoi(getenv("TCL_FLASH40")) : 0;      // tuning hook: force a d = 40 variant (tools/ab)
+    if (d == 40 && var40 == 4) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 3) return launch_flash<40, 48, 64, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
 // Per tile and query block: S^T = K.Q^T (swapped operands: lane l owns query l&31, so row max/sum are in-lane + one exchange
 // with lane l+32), online softmax with lazy rescale (only when some running max grows by more than 2^6), P stays in registers
 // as the B operand of O^T += V^T.P^T; row sums come out of the same MFMA through the ones-row of the V^T panel.
-__device__ __attribute__((aligned(16))) unsigned g_flash_zero[64];
+// filler source for the DMA pieces behind a stage's end: every lane reads 16 B at lane * 16, so it must span a whole 1 KiB piece (a 256-B
+// array let lanes 16-63 read past it -- whatever followed in the code object's data segment, or a fault when that was the segment's end)
+__device__ __attribute__((aligned(1024))) unsigned g_flash_zero[256];
 
 // max over the two 32-lane halves without the LDS round trip of a shuffle: v_permlane32_swap exchanges a's upper half with b's lower half
 __device__ __forceinline__ float xhalf_max(float v) {

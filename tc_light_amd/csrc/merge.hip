@@ -203,14 +203,19 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
     const int tps = (tiles_dst + nsplit - 1) / nsplit, t0 = split * tps, t1 = min(t0 + tps, tiles_dst);
     if (strip * 128 >= na || t0 >= t1) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, col = lane & 31;
-    const _Float16* zero = (const _Float16*)g_tome_zero;
-    // DMA roles: wave w stages pieces 4w .. 4w+3 (8 rows x 128 B each); lane -> row rr of the piece, LDS chunk position ch
+    // DMA roles: wave w stages pieces 4w .. 4w+3 (8 rows x 128 B each); lane -> row rr of the piece, LDS chunk position ch.  A piece's
+    // source is a SCALAR base (tile, k stage, piece: s_add / s_addc) plus one of two per-lane byte offsets (the swizzle term (R >> 1) & 7 of
+    // row R = 8 piece + rr only depends on the piece's parity): the per-lane 64-bit multiply-add, bounds select and zero page of the
+    // first version cost ~8 vector instructions per piece, 31 per K stage next to its 16 MFMAs.  No bounds test at all: the last tile of
+    // the sweep is moved back to rows [nb - 128, nb) (needs nb >= 128, host-checked) -- rows seen twice leave a running maximum and its
+    // lowest index unchanged.
     const int rr = lane >> 3, ch = lane & 7;
+    const int voff0 = rr * (C * 2) + ((ch ^ (rr >> 1)) << 4), voff1 = rr * (C * 2) + ((ch ^ (4 + (rr >> 1))) << 4);
     const int si = strip * 128 + wid * 32 + col;                                   // this lane's src column
     const long srow = si < na ? (long)(si < a_split ? si : si + a_gap) * C : -1;
     const int ntl = t1 - t0, nstep = ntl * NST;
-    half2v pm = {(_Float16)(-65504.f), (_Float16)(-65504.f)};                       // running maxima of the lane's even / odd accumulator elements
-    int bi0 = 0x7fffffff, bi1 = 0x7fffffff;                                         // concatenated dst index where each was first attained
+    _Float16 pm = (_Float16)(-65504.f);                                             // running maximum of the lane's f16-rounded scores
+    int bi = 0x7fffffff;                                                            // concatenated dst index where it was first attained
     for (int bb = 0; bb < Bt; ++bb) {
         const _Float16* base = metric + (long)bb * bstride;
         half8 bfr[C / 16];                                                          // B operand: src column, k = 16 ks + 8 hl .. + 7
@@ -225,11 +230,12 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
         int i_t = 0, i_k = 0;                                                       // (tile, stage) of the step being ISSUED
 #define T320_ISSUE(BUF)                                                                                                       \
         {                                                                                                                     \
+            const int dj0_ = min((t0 + i_t) * 128, nb - 128);                                                                 \
+            const char* sb_ = (const char*)base + ((long)(b0 + dj0_ + wid * 32) * C + i_k * 64) * 2;                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
-                const int piece = wid * 4 + i, R = piece * 8 + rr, dj = (t0 + i_t) * 128 + R;                                \
-                const _Float16* src_ = dj < nb ? base + (long)(b0 + dj) * C + i_k * 64 + ((ch ^ ((R >> 1) & 7)) << 3) : zero; \
+                const char* src_ = sb_ + i * (8 * C * 2) + ((i & 1) ? voff1 : voff0);                                         \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                         \
-                                                 (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + piece * 1024), 16, 0, 0); \
+                                                 (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + (wid * 4 + i) * 1024), 16, 0, 0); \
             }                                                                                                                 \
             if (++i_k == NST) { i_k = 0; ++i_t; }                                                                             \
         }
@@ -268,45 +274,30 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
                 }
                 buf = buf == 2 ? 0 : buf + 1;
             }
-            // ---- score tile (128 dst x 32 src per wave) -> running maxima
-            const int dj0 = (t0 + tl) * 128, cat0 = bb * nb + dj0 + 4 * hl;
-            const bool tail = dj0 + 128 > nb;                                       // wave-uniform: rows past nb were fed zeros
+            // ---- score tile (128 dst x 32 src per wave) -> running maximum.  f32 -> f16 rounding is monotonic, so the maximum of the 16
+            // rounded scores a lane holds of a 32-row tile is the rounded f32 maximum: 8 v_max3 + one conversion instead of 8 cvt_pk + 8
+            // pk_max; the conversions of all 16 and the lowest-index scan run only when the running maximum grew (~ln(tiles) times).
+            const int dj0 = min((t0 + tl) * 128, nb - 128), cat0 = bb * nb + dj0 + 4 * hl;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                half2v hp[8];
+                float t = fmaxf(fmaxf(acc[a][0], acc[a][1]), acc[a][2]);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) hp[q] = half2v{(_Float16)acc[a][2 * q], (_Float16)acc[a][2 * q + 1]};
-                if (tail) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int d0 = dj0 + a * 32 + 4 * hl + ((2 * q) & 3) + 8 * ((2 * q) >> 2);
-                        if (d0 >= nb) hp[q][0] = (_Float16)(-65504.f);
-                        if (d0 + 1 >= nb) hp[q][1] = (_Float16)(-65504.f);
-                    }
-                }
-                half2v tm = hp[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) tm = __builtin_elementwise_max(tm, hp[q]);
-                const half2v np = __builtin_elementwise_max(pm, tm);
-                const unsigned chg = __builtin_bit_cast(unsigned, np) ^ __builtin_bit_cast(unsigned, pm);
-                if (__any(chg != 0u)) {                                             // some lane's running maximum grew inside this 32-row tile
+                for (int r = 3; r < 15; r += 2) t = fmaxf(fmaxf(t, acc[a][r]), acc[a][r + 1]);
+                t = fmaxf(t, acc[a][15]);
+                const _Float16 th = (_Float16)t;
+                if (__any(th > pm)) {                                               // some lane's running maximum grew inside this 32-row tile
                     asm volatile("; record");                                       // (a real branch: the scan below is the expensive part)
-                    int ilo = 0, ihi = 0;                                           // lowest element attaining the new maximum (descending scan)
+                    int rlo = 0;                                                    // lowest element attaining the tile maximum (descending scan)
 #pragma unroll
-                    for (int q = 7; q >= 0; --q) { ilo = hp[q][0] == np[0] ? q : ilo; ihi = hp[q][1] == np[1] ? q : ihi; }
-                    const int rl = 2 * ilo, rh = 2 * ihi + 1;
-                    if (chg & 0xFFFFu) bi0 = cat0 + a * 32 + (rl & 3) + 8 * (rl >> 2);
-                    if (chg >> 16) bi1 = cat0 + a * 32 + (rh & 3) + 8 * (rh >> 2);
+                    for (int r = 15; r >= 0; --r) rlo = (_Float16)acc[a][r] == th ? r : rlo;
+                    if (th > pm) { pm = th; bi = cat0 + a * 32 + (rlo & 3) + 8 * (rlo >> 2); }
                 }
-                pm = np;
             }
         }
 #undef T320_ISSUE
         __builtin_amdgcn_s_barrier();                                               // everyone is done reading the ring before the next batch refills it
     }
-    const _Float16 v = pm[0] > pm[1] ? pm[0] : pm[1];
-    const int idx = pm[0] > pm[1] ? bi0 : (pm[1] > pm[0] ? bi1 : min(bi0, bi1));
-    unsigned long long best = ((unsigned long long)sortable16(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+    unsigned long long best = ((unsigned long long)sortable16(pm) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bi);
     const unsigned long long other = __shfl_xor(best, 32, 64);
     best = other > best ? other : best;
     if (hl == 0 && si < na) atomicMax(keys + si, best);
@@ -502,7 +493,7 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
         set = true;
     }
     static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
-    if (affine && C == 320 && use320) {
+    if (affine && C == 320 && nb >= 128 && use320) {
         int nsplit = 1;
         while (nsplit < 8 && (long)ts * nsplit < 768) nsplit *= 2;
         while (nsplit > 1 && cdiv(td, nsplit) < 2) nsplit /= 2;

@@ -189,21 +189,22 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 // issue cycles as the tile's MFMAs) becomes a RUNNING packed-f16 maximum in registers: per 32-row MFMA tile 8 cvt_pk + 8 pk_max, and
 // the index scan (v_cmp + v_cndmask per element) runs only when some lane's running maximum actually grew -- record-breaking events,
 // ~ln(tiles) per column.  No per-tile atomics: one atomicMax per src row and dst split at the end.  LDS holds only dst rows: 64-wide K
-// stages (128 B per row, 16 KiB per stage, 3-slot ring), 16 MFMAs per wave and barrier instead of 8; rows are gathered by arithmetic
+// stages (128 B per row, 16 KiB per stage, 4-slot ring), 32 MFMAs per wave and barrier instead of 8; rows are gathered by arithmetic
 // (no index loads in the loop, so the counted vmcnt only ever sees the LDS-DMA).  XCD x sweeps dst split x % nsplit: its L2 holds one range.
 // LDS image of a stage: row R at R * 128, its 16-B chunk g stored at position g ^ ((R >> 1) & 7): the 16-lane groups of a ds_read_b128
 // (MI355X_MICROARCH.md, LDS table) then touch 16 distinct slots of the 256-B bank window.
-__global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
+template <int NW>        // waves per block: 4 (128-src strip, two blocks per CU) or 8 (256-src strip, one block per CU: half the dst DMA per MFMA)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
                                                           int b0, int nb, int tiles_dst, int nsplit, unsigned long long* __restrict__ keys) {
-    constexpr int C = 320, NST = C / 64, STAGE = 128 * 128;
+    constexpr int C = 320, NST = C / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;       // src strip width, DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
     const int bid = blockIdx.x, x = bid & 7, per = 8 / nsplit;
     const int split = x & (nsplit - 1), strip = (bid >> 3) * per + x / nsplit;
     const int tps = (tiles_dst + nsplit - 1) / nsplit, t0 = split * tps, t1 = min(t0 + tps, tiles_dst);
-    if (strip * 128 >= na || t0 >= t1) return;
+    if (strip * SW >= na || t0 >= t1) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, col = lane & 31;
-    // DMA roles: wave w stages pieces 4w .. 4w+3 (8 rows x 128 B each); lane -> row rr of the piece, LDS chunk position ch.  A piece's
+    // DMA roles: wave w stages pieces NP w .. NP w + NP - 1 (8 rows x 128 B each); lane -> row rr of the piece, LDS chunk position ch.  A piece's
     // source is a SCALAR base (tile, k stage, piece: s_add / s_addc) plus one of two per-lane byte offsets (the swizzle term (R >> 1) & 7 of
     // row R = 8 piece + rr only depends on the piece's parity): the per-lane 64-bit multiply-add, bounds select and zero page of the
     // first version cost ~8 vector instructions per piece, 31 per K stage next to its 16 MFMAs.  No bounds test at all: the last tile of
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
     // lowest index unchanged.
     const int rr = lane >> 3, ch = lane & 7;
     const int voff0 = rr * (C * 2) + ((ch ^ (rr >> 1)) << 4), voff1 = rr * (C * 2) + ((ch ^ (4 + (rr >> 1))) << 4);
-    const int si = strip * 128 + wid * 32 + col;                                   // this lane's src column
+    const int si = strip * SW + wid * 32 + col;                                    // this lane's src column
     const long srow = si < na ? (long)(si < a_split ? si : si + a_gap) * C : -1;
     const int ntl = t1 - t0, nstep = ntl * NST;
     _Float16 pm = (_Float16)(-65504.f);                                             // running maximum of the lane's f16-rounded scores
@@ -231,26 +232,30 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
 #define T320_ISSUE(BUF)                                                                                                       \
         {                                                                                                                     \
             const int dj0_ = min((t0 + i_t) * 128, nb - 128);                                                                 \
-            const char* sb_ = (const char*)base + ((long)(b0 + dj0_ + wid * 32) * C + i_k * 64) * 2;                          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+            const char* sb_ = (const char*)base + ((long)(b0 + dj0_ + wid * (8 * NP)) * C + i_k * 64) * 2;                    \
+            _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                 \
                 const char* src_ = sb_ + i * (8 * C * 2) + ((i & 1) ? voff1 : voff0);                                         \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                         \
-                                                 (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + (wid * 4 + i) * 1024), 16, 0, 0); \
+                                                 (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + (wid * NP + i) * 1024), 16, 0, 0); \
             }                                                                                                                 \
             if (++i_k == NST) { i_k = 0; ++i_t; }                                                                             \
         }
         T320_ISSUE(0);
         if (nstep > 1) T320_ISSUE(1);
-        int buf = 0, step = 0;
+        int step = 0;
         for (int tl = 0; tl < ntl; ++tl) {
             float16v acc[4];
 #pragma unroll
             for (int kt = 0; kt < NST; ++kt, ++step) {
-                if (step + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // my 4 pieces of this step landed; the next 4 stay in flight
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (step + 2 < nstep) { const int nb_ = buf == 0 ? 2 : buf - 1; T320_ISSUE(nb_); }
-                const char* db = smem + buf * STAGE;
+                // 4-slot ring, two K stages per barrier: steps s, s+1 (s even) are consumed while s+2, s+3 stream into the slots of s-2, s-1
+                // (without any barrier the kernel ran 4-7 % faster; this halves their number)
+                if ((step & 1) == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // my pieces of steps s, s+1 landed (nothing else is in flight)
+                    __builtin_amdgcn_s_barrier();
+                    if (step + 2 < nstep) T320_ISSUE((step + 2) & 3);
+                    if (step + 3 < nstep) T320_ISSUE((step + 3) & 3);
+                }
+                const char* db = smem + (step & 3) * STAGE;
                 // A fragments one k-slice ahead of the MFMAs that use them: the LDS latency of slice ks+1 hides under the 4 MFMAs of slice ks
                 // (with the reads issued right before their MFMAs the waves sat parked 45 % of their cycles, matrix pipe 44 % busy)
                 half8 fa[2][4];
@@ -272,7 +277,6 @@ __global__ __launch_bounds__(256, 2) void k_tome_match320(const _Float16* __rest
                         } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
                     }
                 }
-                buf = buf == 2 ? 0 : buf + 1;
             }
             // ---- score tile (128 dst x 32 src per wave) -> running maximum.  f32 -> f16 rounding is monotonic, so the maximum of the 16
             // rounded scores a lane holds of a 32-row tile is the rounded f32 maximum: 8 v_max3 + one conversion instead of 8 cvt_pk + 8
@@ -485,20 +489,26 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     int* sel = hist + 512;
     unsigned long long* keys = (unsigned long long*)((char*)ws + 4096);
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
-    const size_t lds = (size_t)3 * 256 * 64;
+    const size_t lds = (size_t)3 * 256 * 64, lds320 = (size_t)4 * 128 * 128;
     static bool set = false;
     if (!set) {
         (void)hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_tome_match320, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_tome_match320<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
+        (void)hipFuncSetAttribute((const void*)k_tome_match320<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
         set = true;
     }
     static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
     if (affine && C == 320 && nb >= 128 && use320) {
+        // 8-wave blocks (256-src strips, one per CU: half the dst DMA per MFMA) once the problem fills the chip a few times over in that form
+        // (measured cross-over between 17 280 x 5 760 and 12 672^2); use320 = 4 / 8 forces a form (tools/micro/bench_tome.py)
+        const int nw = use320 == 4 || use320 == 8 ? use320 : ((long)cdiv(na, 256) * td >= 4000 ? 8 : 4);
+        const int tsw = cdiv(na, 32 * nw), slots = nw == 8 ? 256 : 512;
         int nsplit = 1;
-        while (nsplit < 8 && (long)ts * nsplit < 768) nsplit *= 2;
+        while (nsplit < 8 && (long)tsw * nsplit < slots * 3 / 2) nsplit *= 2;
         while (nsplit > 1 && cdiv(td, nsplit) < 2) nsplit /= 2;
-        const int per = 8 / nsplit, groups = cdiv(ts, per);
-        hipLaunchKernelGGL(k_tome_match320, dim3(groups * 8), dim3(256), lds, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
+        const int per = 8 / nsplit, groups = cdiv(tsw, per);
+        if (nw == 8) hipLaunchKernelGGL(k_tome_match320<8>, dim3(groups * 8), dim3(512), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
+        else hipLaunchKernelGGL(k_tome_match320<4>, dim3(groups * 8), dim3(256), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
     } else {
     // each block keeps one dst tile and streams a run of src tiles; runs as long as possible while ~4 blocks per slot (256 CUs x 3) remain
     int spb = (int)((long)ts * td * Bt / 3072);

@@ -1,0 +1,52 @@
+// The instruction mix of one head_dim-40 flash tile (per 32-query block: 6 MFMA 32x32x16, 23 max, 32 exp, 16 cvt_pk, 8 permlane16_swap,
+// 12 MFMA 16x16x32), all operands independent, no LDS / DMA / barrier: what the SIMD's issue port allows for this mix.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/flash_mix.hip -o /tmp/flash_mix && /tmp/flash_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+#define V8(OP) asm volatile(OP " %0, %0\n " OP " %1, %1\n " OP " %2, %2\n " OP " %3, %3\n " OP " %4, %4\n " OP " %5, %5\n " OP " %6, %6\n " OP " %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define EXP8 V8("v_exp_f32")
+#define CVT8 asm volatile("v_cvt_pk_f16_f32 %0, %0, %1\n v_cvt_pk_f16_f32 %1, %1, %2\n v_cvt_pk_f16_f32 %2, %2, %3\n v_cvt_pk_f16_f32 %3, %3, %4\n v_cvt_pk_f16_f32 %4, %4, %5\n v_cvt_pk_f16_f32 %5, %5, %6\n v_cvt_pk_f16_f32 %6, %6, %7\n v_cvt_pk_f16_f32 %7, %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define MAX8 asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_max3_f32 %3, %3, %4, %5\n v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %0\n v_max3_f32 %7, %7, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define PERM8 asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %0, %3\n v_permlane16_swap_b32 %1, %2\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+#define MF32x6 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0); s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0); s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0);
+#define MF16x6 o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o0, 0, 0, 0); o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o1, 0, 0, 0); o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o2, 0, 0, 0); o3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o3, 0, 0, 0); o4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o4, 0, 0, 0); o5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o5, 0, 0, 0);
+// MODE 0: full mix, phases in program order   1: without the maxima   2: without exp   3: MFMAs only   4: vector part only
+// MODE 5: full mix, vector work interleaved between the MFMAs (one MFMA, then ~1/18 of the vector work)
+template <int MODE>
+__global__ void k(unsigned long long* out, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f;
+    unsigned u0 = threadIdx.x, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7;
+    half8 hv = {1, 2, 3, 4, 5, 6, 7, 8};
+    float16v s0 = {0}, s1 = {0};
+    float4v o0 = {0}, o1 = {0}, o2 = {0}, o3 = {0}, o4 = {0}, o5 = {0};
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    for (int lap = 0; lap < 128; ++lap) {      // one lap = one 32-query block x one 64-key tile
+        if (MODE != 4) { MF32x6 }
+        if (MODE != 1 && MODE != 3) { MAX8 MAX8 MAX8 }
+        if (MODE != 2 && MODE != 3) { EXP8 EXP8 EXP8 EXP8 }
+        if (MODE != 3) { CVT8 CVT8 PERM8 }
+        if (MODE != 4) { MF16x6 MF16x6 }
+    }
+    const unsigned long long t1 = clock64();
+    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3) + s0[0] + s1[1] + o0[0] + o1[0] + o2[0] + o3[0] + o4[0] + o5[0];
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { atomicMax(out, t1 - t0); out[1] = (unsigned long long)sink; }
+}
+template <int MODE> void run(const char* name, unsigned long long* d) {
+    for (int w = 1; w <= 4; w *= 2) {
+        hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * w), 0, 0, d, 1.0f);
+        hipMemset(d, 0, 16);
+        hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * w), 0, 0, d, 1.0f);
+        unsigned long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+        printf("%-40s %d wave(s)/SIMD: %7.0f cycles per lap of all the SIMD's waves (%5.0f per wave-lap; matrix pipe 384 per wave-lap -> %4.1f %% busy)\n", name, w,
+               (double)h[0] / 128.0, (double)h[0] / 128.0 / w, 100.0 * 384.0 * w / ((double)h[0] / 128.0) * (MODE == 4 ? 0 : 1));
+    }
+}
+int main() {
+    unsigned long long* d; hipMalloc(&d, 16);
+    run<0>("full mix", d); run<1>("without max", d); run<2>("without exp", d); run<3>("MFMAs only", d); run<4>("vector part only", d);
+    return 0;
+}

@@ -99,10 +99,10 @@ __device__ __forceinline__ float xhalf_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC>
 __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
-                                                  int kv_div, int nqb) {
+                                                  int kv_div, int nqb, int* __restrict__ flags) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = DPV * V_STRIDE * 2, SBYTES = KBYTES + VBYTES;
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
 
     const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
+    if (!SPEC && flags && !flags[bid]) return;      // second pass behind the speculative kernel: only the blocks it flagged
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, ql = lane & 31;
     const int q0 = qb_ * (128 * QB) + wid * (32 * QB);
     const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
@@ -178,6 +179,53 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
 
     // MK = std::true_type: the tile may hold padded keys (only the last one does).  A compile-time switch, not `if (it >= nfull)`: hipcc turns
     // that runtime test into 126 unconditional v_cmp / v_cndmask / v_add per tile -- half of this VALU-bound loop's vector instructions.
+    // SPEC (head_dim 40): the loop is bound by vector ISSUE (tools/micro/flash_mix.hip: its instruction mix allows the matrix pipe 52 % with
+    // the row maxima, 62 % without), and the row maximum is the one term that only guards the f16 range of P.  So the shift m is kept OFF = 4
+    // bits ABOVE the running row maximum (P <= 2^-4 in the common case), P is computed without looking at the scores, and the guard reads
+    // the result: OR of the packed P registers, bit 14 of a half set <=> some P >= 2 <=> a score rose 2^5 above the maximum the shift was
+    // made for.  The guard is evaluated AFTER the tile's PV MFMAs are issued (P in [2, 65504] is still exact, so that PV was right): then
+    // `rebase` recomputes the tile's scores from the K tile still in LDS, takes the exact row maxima and moves shift, Q column and O.
+    // What this cannot catch in time is a P beyond the f16 range (a score 2^20 above everything the row had seen, inside one tile): the
+    // row sum then comes out inf / NaN, the block flags itself and the launch that follows (the exact-maximum kernel, gated by the flags)
+    // redoes that block.  Tile 0 starts with a rebase (there is no shift yet).  Tiles with padded keys (the last one) take the exact-maximum
+    // path below -- same shift convention, any shift is valid there -- so the speculative code carries no key masks.
+    constexpr float OFF = 4.f;
+    static_assert(!SPEC || (FOLD && PV16), "the speculative softmax is the head_dim-40 path");
+    auto rebase = [&](const int it, const bool first) __attribute__((always_inline)) {
+        if constexpr (SPEC) {
+        const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float16v s[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NQK; ++ks)
+                    s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(kt + (blk * 32 + ql) * KS + 8 * hl + ks * 16), qf[qb][ks], s[blk], 0, 0, 0);
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+            mx = xhalf_max(mx) + OFF;                                            // (scores are relative to the current shift)
+            const float mn = (float)(_Float16)(m[qb] + (first ? mx : fmaxf(mx, 0.f)));      // the shift only ever grows; kept f16-representable
+            const float delta = mn - m[qb], alpha = __builtin_amdgcn_exp2f(-delta);
+            m[qb] = mn;
+            if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);                    // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
+            if (!first) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const float aq = __shfl(alpha, (lane & 15) + 16 * qt, 64);   // this accumulator's query sits in another lane of the S^T layout
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) o16[qb][qt][t] *= aq;
+                }
+            }
+        }
+        }
+    };
     auto tile = [&](const int it, auto MK) __attribute__((always_inline)) {
         const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
         const _Float16* vt = kt + KV_TILE * KS;
@@ -223,6 +271,36 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) sacc[qb][blk][r] = -1e30f; }
+        }
+        if constexpr (SPEC && !mask) {
+            unsigned orv = 0;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float16v (&s)[2] = sacc[qb];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
+                    u32x4 x = __builtin_bit_cast(u32x4, pf[qb][blk][0]), y = __builtin_bit_cast(u32x4, pf[qb][blk][1]);
+                    orv |= x[0] | x[1] | x[2] | x[3] | y[0] | y[1] | y[2] | y[3];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                        x[w] = sw[0]; y[w] = sw[1];
+                    }
+                    const half8 p0 = __builtin_bit_cast(half8, x), p1 = __builtin_bit_cast(half8, y);      // queries 0-15 | 16-31
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) {
+                        o16[qb][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p0, o16[qb][0][t], 0, 0, 0);
+                        o16[qb][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p1, o16[qb][1][t], 0, 0, 0);
+                    }
+                }
+            }
+            if (__any((orv & 0x40004000u) != 0u)) {
+                asm volatile("; rebase");                                       // keeps this rare path a real branch
+                rebase(it, false);
+            }
+            return;
         }
         // row maxima of every query block first, then ONE (rare) branch for all re-basing of the tile, so that the common path below --
         // exponentials, conversions and the PV MFMAs of all query blocks -- is a single basic block the scheduler can interleave
@@ -354,6 +432,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
             __builtin_amdgcn_s_barrier();             // tiles it, it+1 landed for every wave; everyone is done with it-2, it-1
             if (it + 2 < nt) FLASH_ISSUE(it + 2);
             if (it + 3 < nt) FLASH_ISSUE(it + 3);
+            if (SPEC && it == 0) rebase(0, true);
             tile(it, std::false_type{});
             tile(it + 1, std::false_type{});
         }
@@ -377,6 +456,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
             __builtin_amdgcn_s_barrier();             /* every wave's pieces of tile it landed; everyone is done with it-1 */ \
             if (it + NSTG - 1 < nt) FLASH_ISSUE(it + NSTG - 1);                                                               \
+            if (SPEC && !decltype(MK)::value && it == 0) rebase(0, true);                                                     \
             tile(it, MK);                                                                                                     \
         }
         int it = 0;
@@ -385,6 +465,16 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
 #undef FLASH_STEP
     }
 #undef FLASH_ISSUE
+    if constexpr (SPEC) {
+        // row sums (O^T row 40) that are not finite and positive: some P left the f16 range -> this block is redone by the gated exact kernel
+        bool bad = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { const float l = __shfl(o16[qb][qt][2][0], 32 + (lane & 15), 64); bad |= !(l > 0.f && l < 3e38f); }
+        const int anybad = __syncthreads_or(bad);
+        if (tid == 0) flags[bid] = anybad;
+    }
     // ---- epilogue
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -663,13 +753,13 @@ static void flash_prof_drain(bool all) {
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
-                        int d, int ldo, long obs, int kv_div, hipStream_t st) {
+                        int d, int ldo, long obs, int kv_div, hipStream_t st, int* flags = nullptr, bool count = true) {
     constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -677,8 +767,8 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
         if (g_prof.ev.size() > 8192) flash_prof_drain(false);       // a 300-frame pass has ~1e5 launches: keep the live event count bounded
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb);
-    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; }
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags);
+    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -717,7 +807,7 @@ int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches)
 }
 
 // panel sizes: Tqp = ceil256(Tq), Tkp = ceil64(Tk), DP = ceil16(d), DPV = ceil32(d); K rows DP+8 halves, V^T tiles DPV x V_STRIDE
-size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 256) * rup(d, 16) * 2 + 256; }
+size_t tcl_attention_q_bytes(int B, int H, int Tq, int d) { return (size_t)B * H * rup(Tq, 256) * rup(d, 16) * 2 + 256 + (size_t)B * H * (rup(Tq, 256) / 128) * 4; }      // Q panel + per-block flags
 size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
     return ((size_t)Bkv * H * rup(Tk, 64) * (rup(d, 16) + 8) + (size_t)Bkv * H * (rup(Tk, 64) / 64) * rup(d, 32) * V_STRIDE) * 2 + 2048;
 }
@@ -752,6 +842,14 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (d == 40 && var40 == 4) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 3) return launch_flash<40, 48, 64, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40 && qb2 && var40 == 0) {
+        // speculative softmax (no row maxima in the loop), then the exact kernel over the blocks that flagged an f16 overflow of P (normally none:
+        // its blocks read one flag and leave)
+        int* flags = (int*)((char*)ws_q + (((size_t)B * H * Tqp * DP * 2 + 255) / 256) * 256);
+        int rc = launch_flash<40, 48, 64, 2, 4, 2, 0, 1>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags);
+        if (rc == TCL_OK) rc = launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags, false);
+        return rc;
+    }
     if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
                                           : launch_flash<40, 48, 64, 1, 2, 1, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);

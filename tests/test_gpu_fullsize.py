@@ -93,6 +93,43 @@ def test_attention_rebase_path_spiked_scores(L):
     assert rel(o[:, sp], ref[:, pos]) < 3e-3               # the spiked rows themselves: output ~ v[kj] (one key dominates)
 
 
+@pytest.mark.parametrize("gain,flagged", [(1.6, False), (3.2, True)])
+def test_attention_speculative_softmax_guard_and_fallback(L, gain, flagged):
+    """head_dim 40, large launches: the softmax runs without row maxima (attn.hip SPEC) -- the shift sits 4 bits above the running maximum, a
+    guard on the packed P registers (some P >= 2) triggers the rebase after the tile's PV, and a P beyond the f16 range flags the block for
+    the exact-maximum kernel that follows.  gain 1.6: late keys ~8 bits above everything their row has seen -> guard + rebase, NO block may be
+    flagged; gain 3.2: ~20 bits above for the paired query (P overflows inside the tile: the blocks holding those rows must be flagged and
+    redone) and at most ~9 bits for every other row (no other block may be flagged).  (test_attention_rebase_path_spiked_scores, gain 9,
+    flags every block: such a key is 2^16 above the shift for some row of each.)  Both: all rows of the spiked waves and their neighbours
+    against an f32 reference."""
+    d, B, Tq, Tk, Hh = 40, 2, 16400, 16950, 8
+    C = Hh * d
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    k = torch.randn(B, Tk, C, device="cuda", generator=g).to(H)
+    v = torch.randn(B, Tk, C, device="cuda", generator=g).to(H)
+    spikes = [(9, 64 * 90 + 5), (40, 64 * 91 + 33), (77, 64 * 180 + 63), (301, 64 * 3 + 1), (302, 64 * 4 + 2), (9000, Tk - 1), (9001, 64 * 260), (16399, 64 * 151 + 7)]
+    for qi, kj in spikes:
+        k[:, kj] = (q[:, qi].float() * gain).to(H)
+    o = torch.zeros(B, Tq, C, device="cuda", dtype=H)
+    wq, wkv = torch.zeros(L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device="cuda"), ws_bytes(L.tcl_attention_kv_bytes(B, Hh, Tk, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, 1, 1, wq, wkv, st())
+    Tqp, nblk = -(-Tq // 256) * 256, B * Hh * -(-Tq // 256)
+    off = -(-(B * Hh * Tqp * 48 * 2) // 256) * 256                   # per-block flags behind the Q panel (attn.hip)
+    flags = wq[off:off + 4 * nblk].view(torch.int32)
+    assert set(flags.unique().tolist()) <= {0, 1}
+    nflag = int(flags.sum())
+    assert (nflag > 0) == flagged and nflag <= B * Hh * 4, nflag                  # the spiked rows sit in 4 of the 65 query blocks
+    rows = torch.tensor(sorted({r for qi, _ in spikes for r in range(max(qi - 65, 0), min(qi + 66, Tq))}), device="cuda")
+    qq = q[:, rows].float().view(B, -1, Hh, d).transpose(1, 2)
+    kk, vv = (t.float().view(B, Tk, Hh, d).transpose(1, 2) for t in (k, v))
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, -1, C)
+    assert torch.isfinite(o).all()
+    assert rel(o[:, rows], ref) < 3e-3
+    sp = torch.tensor([qi for qi, _ in spikes], device="cuda")
+    assert rel(o[:, sp], ref[:, torch.searchsorted(rows, sp)]) < 3e-3
+
+
 @pytest.mark.parametrize("na,nb,C,ratio", [(32400, 10800, 320, 0.6),     # local (random-frame) merge of a 4-frame chunk at level 0
                                            (23760, 23760, 320, 0.5),     # global merge against an equally long bank
                                            (8100, 2700, 640, 0.6),       # level 1

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     // redoes that block.  Tile 0 starts with a rebase (there is no shift yet).  Tiles with padded keys (the last one) take the exact-maximum
     // path below -- same shift convention, any shift is valid there -- so the speculative code carries no key masks.
     constexpr float OFF = 4.f;
+    unsigned orv = 0;                                 // SPEC: OR of the packed P registers since the last guard test
     static_assert(!SPEC || (FOLD && PV16), "the speculative softmax is the head_dim-40 path");
     auto rebase = [&](const int it, const bool first) __attribute__((always_inline)) {
         if constexpr (SPEC) {
@@ -273,7 +274,6 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                     for (int r = 0; r < 16; ++r) { int kv = it * KV_TILE + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl; if (kv >= Tk) sacc[qb][blk][r] = -1e30f; }
         }
         if constexpr (SPEC && !mask) {
-            unsigned orv = 0;
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float16v (&s)[2] = sacc[qb];
@@ -296,9 +296,12 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
                     }
                 }
             }
-            if (__any((orv & 0x40004000u) != 0u)) {
-                asm volatile("; rebase");                                       // keeps this rare path a real branch
-                rebase(it, false);
+            if constexpr (TPB == 1) {
+                if (__any((orv & 0x40004000u) != 0u)) {
+                    asm volatile("; rebase");                                   // keeps this rare path a real branch
+                    rebase(it, false);
+                }
+                orv = 0;
             }
             return;
         }
@@ -435,6 +438,16 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
             if (SPEC && it == 0) rebase(0, true);
             tile(it, std::false_type{});
             tile(it + 1, std::false_type{});
+            if constexpr (SPEC) {
+                // ONE guard test per pair of tiles, behind both tiles' work (the OR result is long there: no stall on it, and the pair is one
+                // basic block); both K tiles are still in their ring slots.  The second rebase sees the first one's shift.
+                if (__any((orv & 0x40004000u) != 0u)) {
+                    asm volatile("; rebase");                                   // keeps this rare path a real branch
+                    rebase(it, false);
+                    rebase(it + 1, false);
+                }
+                orv = 0;
+            }
         }
         for (; it < nt; it += 2) {                    // the last one or two tiles (same ring protocol), masked variant
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

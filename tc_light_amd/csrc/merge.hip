@@ -499,9 +499,11 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     }
     static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
     if (affine && C == 320 && nb >= 128 && use320) {
-        // 8-wave blocks (256-src strips, one per CU: half the dst DMA per MFMA) once the problem fills the chip a few times over in that form
-        // (measured cross-over between 17 280 x 5 760 and 12 672^2); use320 = 4 / 8 forces a form (tools/micro/bench_tome.py)
-        const int nw = use320 == 4 || use320 == 8 ? use320 : ((long)cdiv(na, 256) * td >= 4000 ? 8 : 4);
+        // 4-wave blocks by default.  The 8-wave form (256-src strips, one block per CU, half the dst DMA per MFMA) is 3-6 % faster with the GPU
+        // to itself from ~13k x 13k tokens up, but in the pipeline the matching chain runs on a side stream beside the flash kernel: a 512-thread
+        // block (352 VGPRs per SIMD lane, 64 KiB LDS) only starts on a CU that holds NO flash block, where a 4-wave block shares one with a flash
+        // block -- in the profiled pass the 8-wave launches took 2.2 ms on average against 0.9 alone.  use320 = 8 selects it (tools/micro/bench_tome.py).
+        const int nw = use320 == 8 ? 8 : 4;
         const int tsw = cdiv(na, 32 * nw), slots = nw == 8 ? 256 : 512;
         int nsplit = 1;
         while (nsplit < 8 && (long)tsw * nsplit < slots * 3 / 2) nsplit *= 2;

@@ -170,6 +170,32 @@ def unet_flops_unmerged(B, h, w, L):
     return fl + 2.0 * B * h * w * 9 * 320 * 4
 
 
+def flash_alone(shape, dev, n=60):
+    """The dominant kernel on the largest launch shape of the pass with the GPU to itself (in the pass the VidToMe matching chain shares the CUs
+    from its side stream): n launches of tcl_attention_f16 (pack kernels included) on random q/k/v, torch events on the launch stream."""
+    from tc_light_amd.lib import lib, stream
+    B, Hh, Tq, Tk = shape
+    L, d = lib(), 40
+    C = Hh * d
+    q, k, v = (torch.randn(B, t, C, device=dev).half() for t in (Tq, Tk, Tk))
+    o = torch.empty_like(q)
+    wq = torch.empty(L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=dev)
+    wkv = torch.empty(L.tcl_attention_kv_bytes(B, Hh, Tk, d), dtype=torch.uint8, device=dev)
+    f = lambda: L.tcl_attention_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, o, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, 1, 1, wq, wkv, stream())
+    for _ in range(20):
+        f()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record(); torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / n
+    ach = 4.0 * B * Hh * Tq * Tk * d / (ms * 1e-3) / 1e12
+    return {"achieved": ach, "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": ms, "shape": {"B": B, "H": Hh, "Tq": Tq, "Tk": Tk, "d": d},
+            "how": f"{n} back-to-back attention calls (Q/K/V packing included) on the largest launch shape of the pass, nothing else on the GPU"}
+
+
 def measured_traffic():
     """HBM-side bytes per k_flash<40,...> launch from the committed PMC passes (tools/collect_profiles.sh -> profiles/*_flash40_traffic.json).
     PMC counters cannot be read from inside the timed process, so the newest committed measurement of this same command is reported
@@ -246,7 +272,9 @@ def main():
         if profile:
             ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
             lib().tcl_flash_profile_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
-            prof = (ms.value, fl.value, cnt.value)
+            shp = (ctypes.c_int * 4)()
+            lib().tcl_flash_profile_shape(shp)
+            prof = (ms.value, fl.value, cnt.value, tuple(shp))
             unet.count_flops = False
         return out, info, prof
 
@@ -276,7 +304,7 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        ms, fl, cnt = prof
+        ms, fl, cnt = prof[:3]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         is_base = (n_total, H, W, n_steps, a.epochs_exposure, a.epochs, a.no_multi_axis) == (300, 720, 1280, BASE_STEPS, 35, 70, False)
         traffic, traffic_src = measured_traffic()
@@ -303,6 +331,8 @@ def main():
                          "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": unet.flops / 1e12,
                          "how": "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"},
         }
+        if len(prof) > 3 and prof[3][2] > 0:
+            res["roofline"]["alone"] = flash_alone(prof[3], dev)
         if prof_ex and prof_ex[0] > 0:
             ax = prof_ex[1] / (prof_ex[0] * 1e-3) / 1e12
             res["roofline"]["exclusive"] = {"achieved": ax, "frac": ax / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": prof_ex[0] / max(prof_ex[2], 1),

@@ -211,9 +211,11 @@ int tcl_flowid(const float* frames, const float* fwd_flows, const float* masks, 
                void* ws, hipStream_t st);
 
 /* Measurement aid (bench.py roofline leg): bracket every flash-kernel launch (head_dim == dfilter, 0 = all) with HIP events
- * on its own stream; _end returns the summed kernel time, the algorithmic FLOPs 4*B*H*Tq*Tk*d and the launch count. */
+ * on its own stream; _end returns the summed kernel time, the algorithmic FLOPs 4*B*H*Tq*Tk*d and the launch count (a launch =
+ * one attention call: the speculative kernel and the gated exact kernel behind it are timed together). */
 int tcl_flash_profile_begin(int dfilter);
 int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches);
+int tcl_flash_profile_shape(int* shape4);        /* (B, H, Tq, Tk) of the largest launch profiled since _begin */
 
 /* ---- MemFlowNet correlation lookup (utils/evaluation/memflow/core/Networks/MemFlowNet/corr.py:74-120 CorrBlock,
  * computed on demand like the reference's unused alt_cuda_corr extension -- the all-pairs volume never exists).  f32, NHWC feature maps.

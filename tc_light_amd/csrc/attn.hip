@@ -750,7 +750,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_flash40p(const _Fl
 // ---- optional in-library timing of the flash kernel (bench.py roofline leg): HIP events recorded on the launch stream
 #include <vector>
 #include <deque>
-struct FlashProf { bool on = false; int dfilter = 0; std::deque<hipEvent_t> ev; double flops = 0.0, ms = 0.0; long launches = 0; };
+struct FlashProf { bool on = false; int dfilter = 0; std::deque<hipEvent_t> ev; double flops = 0.0, ms = 0.0; long launches = 0; int big[4] = {0, 0, 0, 0}; double bigfl = 0.0; };
 static FlashProf g_prof;
 // resolve (elapsed time -> g_prof.ms) and free the oldest event pairs: all of them (blocking) or only those already complete
 static void flash_prof_drain(bool all) {
@@ -781,7 +781,7 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
     }
     hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags);
-    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { g_prof.flops += 4.0 * B * H * (double)Tq * Tk * d; g_prof.launches++; } }
+    if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -808,7 +808,9 @@ static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 extern "C" {
 
 // Timing of the flash kernel launches (all head dims, or only head_dim == dfilter) with HIP events on their stream.
-int tcl_flash_profile_begin(int dfilter) { g_prof.on = true; g_prof.dfilter = dfilter; g_prof.flops = 0.0; g_prof.ms = 0.0; g_prof.launches = 0; g_prof.ev.clear(); return TCL_OK; }
+int tcl_flash_profile_begin(int dfilter) { g_prof.on = true; g_prof.dfilter = dfilter; g_prof.flops = 0.0; g_prof.ms = 0.0; g_prof.launches = 0; g_prof.bigfl = 0.0; g_prof.ev.clear(); return TCL_OK; }
+// -> (B, H, Tq, Tk) of the largest launch profiled since begin
+int tcl_flash_profile_shape(int* shape4) { TCL_CHECK_ARG(shape4); for (int i = 0; i < 4; ++i) shape4[i] = g_prof.big[i]; return TCL_OK; }
 // -> total kernel ms, algorithmic FLOPs (4*B*H*Tq*Tk*d per launch) and launch count since begin; synchronises the events.
 int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches) {
     TCL_CHECK_ARG(total_ms && total_flops && launches);

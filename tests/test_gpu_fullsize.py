@@ -255,7 +255,8 @@ def test_unet_pass_full_size_deterministic(Hh, Ww, Fs, Lt):
                                                          (5760, 3, 2, 0, 0, 0.9),         # yt plane of a 64-frame window, dst = last frame, ragged tiles
                                                          (0, 0, 0, 63360, 31680, 0.5),    # config 3 two-set (global) merge, local tokens are src
                                                          (0, 0, 0, 40777, 17017, 0.8),    # ragged sizes, config 4's global ratio
-                                                         (300, 4, 1, 0, 0, 0.6)])         # smaller than one dst split
+                                                         (300, 4, 1, 0, 0, 0.6),          # smaller than one dst split; last dst tile moved back
+                                                         (100, 4, 1, 0, 0, 0.6)])         # fewer than 128 dst tokens: the strip kernel hands over to the tile kernel
 def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len, ratio):
     """k_tome_match320 (src strip in registers, running maximum over the dst sweep; taken through tcl_tome_match_affine_f16 for C = 320)
     must produce the SAME maps as the general tile-epilogue kernel (tcl_tome_match_f16), bit for bit: same MFMA, same K order, same key."""

@@ -18,11 +18,11 @@ fi
 for c in FETCH_SIZE WRITE_SIZE; do     # separate counter passes, 2 denoising steps of the same workload (60 of the 300 frames keep them short)
   rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $GRAFT_REPO_ROOT/bench.py --frames 60 --steps 2 --warmup 0 --no_cpu_baseline --no_extras --epochs 0 --epochs_exposure 1 > /dev/null 2>&1
 done
-python $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pm_FETCH_SIZE/pm_counter_collection.csv /tmp/pm_WRITE_SIZE/pm_counter_collection.csv k_flashILi40 > $OUT/flash40_traffic.json
+python $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pm_FETCH_SIZE/pm_counter_collection.csv /tmp/pm_WRITE_SIZE/pm_counter_collection.csv k_flashILi40 k_flashILi40ELi48ELi64ELi2ELi4ELi2ELi0ELi0E > $OUT/flash40_traffic.json
 cat $OUT/flash40_traffic.json; tail -1 $OUT/bench_under_rocprof.json | cut -c1-300
 # SQ counters of the head_dim-40 flash kernel alone (tools/micro/pmc_attn.py: B=2, H=8, T=35640, the merged xy-plane sequence of config 2):
 # MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader cycles), shader cycles = GRBM_GUI_ACTIVE / 8 XCDs
-bash $GRAFT_REPO_ROOT/tools/micro/pmc_run.sh tools/micro/pmc_attn.py k_flashILi40 > $OUT/flash40_sq_counters.txt 2>&1
+bash $GRAFT_REPO_ROOT/tools/micro/pmc_run.sh tools/micro/pmc_attn.py k_flashILi40ELi48ELi64ELi2ELi4ELi2ELi0ELi1E > $OUT/flash40_sq_counters.txt 2>&1      # the speculative kernel (the gated exact one behind it only reads its flags)
 python - "$OUT/flash40_sq_counters.txt" <<'PY' >> $OUT/flash40_sq_counters.txt
 import sys
 v = {}

@@ -18,6 +18,7 @@ import argparse
 import ctypes
 import json
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL between processes needs dmabuf IPC on this driver (set before HIP starts)
 import sys
 import time
 

@@ -6,6 +6,7 @@ generate.py:607-630).
 Multi-GPU: torchrun --nproc-per-node N run.py ... shards frames over the ranks (tc_light_amd/parallel.py).
 """
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL between processes needs dmabuf IPC on this driver (set before HIP starts)
 import random
 import sys
 

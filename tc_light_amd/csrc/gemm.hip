@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
                     const int gc = (c8 >> 5) * 64 + (c8 & 31);           // 64-column groups [32 value | 32 gate]
                     half8 va = *(const half8*)(Cs + row * CS + gc), vg = *(const half8*)(Cs + row * CS + gc + 32);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * gelu_erf(gf)); }
                     *(half8*)(C + (long)m * ldc + n) = va;
                 }
             }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
                 const int gc = (c8 >> 5) * 64 + (c8 & 31);               // 64-column groups [32 value | 32 gate]
                 half8 va = *(const half8*)(Cs + row * CS + gc), vg = *(const half8*)(Cs + row * CS + gc + 32);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * gelu_erf(gf)); }
                 *(half8*)(C + (long)m * ldc + n) = va;
             }
         }

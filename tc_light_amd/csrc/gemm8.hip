@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
                 if (m < M && n < (N >> 1)) {
                     half8 va = *(const half8*)(Cs + row * CSW + c8), vg = *(const half8*)(Cs + row * CSW + 32 + c8);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * (0.5f * gf * (1.f + erff(gf * 0.70710678f)))); }
+                    for (int q = 0; q < 8; ++q) { float gf = (float)vg[q]; va[q] = (_Float16)((float)va[q] * gelu_erf(gf)); }
                     *(half8*)(C + (long)m * ldc + n) = va;
                 }
             }

@@ -20,16 +20,29 @@ __device__ __forceinline__ int conv_kmap(int k0, int Cin, int& c0) {
     const int tap = k0 / Cin; c0 = k0 - tap * Cin; return tap;
 }
 
+// erf-GELU for epilogues whose input and output are f16: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the f16 rounding of the
+// result) -- one v_rcp, one v_exp and 9 fma / mul instead of libdevice erff's two-branch evaluation (~28 vector instructions per element;
+// the GEGLU epilogue of a K = 320 Linear issues more vector cycles than its ten K steps issue matrix cycles)
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = v * 0.70710678f, ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+    const float erfa = fmaf(-(p * t), e, 1.f);                     // erf(|x|)
+    return 0.5f * v * (1.f + copysignf(erfa, x));
+}
+
 // epilogue activations: 1 SiLU, 3 ReLU, 4 GELU (erf); 0, 2 (GEGLU, applied on column pairs by the caller) and 5 (GELU applied AFTER the
 // residual add, see post_act) leave v unchanged
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return v / (1.f + __expf(-v));
     if (act == 3) return fmaxf(v, 0.f);
-    if (act == 4) return 0.5f * v * (1.f + erff(v * 0.70710678f));
+    if (act == 4) return gelu_erf(v);
     return v;
 }
 
-__device__ __forceinline__ float post_act(float v, int act) { return act == 5 ? 0.5f * v * (1.f + erff(v * 0.70710678f)) : v; }
+__device__ __forceinline__ float post_act(float v, int act) { return act == 5 ? gelu_erf(v) : v; }
 
 int gemm8_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st);

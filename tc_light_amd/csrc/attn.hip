@@ -180,16 +180,23 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     // MK = std::true_type: the tile may hold padded keys (only the last one does).  A compile-time switch, not `if (it >= nfull)`: hipcc turns
     // that runtime test into 126 unconditional v_cmp / v_cndmask / v_add per tile -- half of this VALU-bound loop's vector instructions.
     // SPEC (head_dim 40): the loop is bound by vector ISSUE (tools/micro/flash_mix.hip: its instruction mix allows the matrix pipe 52 % with
-    // the row maxima, 62 % without), and the row maximum is the one term that only guards the f16 range of P.  So the shift m is kept OFF = 4
-    // bits ABOVE the running row maximum (P <= 2^-4 in the common case), P is computed without looking at the scores, and the guard reads
-    // the result: OR of the packed P registers, bit 14 of a half set <=> some P >= 2 <=> a score rose 2^5 above the maximum the shift was
+    // the row maxima, 62 % without), and the row maximum is the one term that only guards the f16 range of P.  So the shift m is kept OFF = 3
+    // bits ABOVE the running row maximum (P <= 2^-3 in the common case; weights below 2^-21 of the row maximum vanish where the textbook P <= 1
+    // keeps them down to 2^-24: measured on rows with a sink key 20 bits above the rest, 3.0e-4 rel-L2 against 2.2e-4 for the exact kernel (5.5e-4 with OFF = 4),
+    // tests/test_gpu_fullsize.py::test_attention_heavy_tail_and_sink_precision), P is computed without looking at the scores, and the guard reads
+    // the result: OR of the packed P registers, bit 14 of a half set <=> some P >= 2 <=> a score rose 4 bits above the maximum the shift was
     // made for.  The guard is evaluated AFTER the tile's PV MFMAs are issued (P in [2, 65504] is still exact, so that PV was right): then
     // `rebase` recomputes the tile's scores from the K tile still in LDS, takes the exact row maxima and moves shift, Q column and O.
-    // What this cannot catch in time is a P beyond the f16 range (a score 2^20 above everything the row had seen, inside one tile): the
+    // What this cannot catch in time is a P beyond the f16 range (a score 19 bits above everything the row had seen, inside one tile): the
     // row sum then comes out inf / NaN, the block flags itself and the launch that follows (the exact-maximum kernel, gated by the flags)
-    // redoes that block.  Tile 0 starts with a rebase (there is no shift yet).  Tiles with padded keys (the last one) take the exact-maximum
+    // redoes that block.  Tile 0 starts with a rebase (there is no shift yet).  Scores that keep climbing along the key sequence make every
+    // tile pair pay a rebase (keys scaled by a ramp 0.3 .. 6 along the sequence: 567 against 758 TFLOP/s for the exact kernel); keys in
+    // token order have no such trend.  Tiles with padded keys (the last one) take the exact-maximum
     // path below -- same shift convention, any shift is valid there -- so the speculative code carries no key masks.
-    constexpr float OFF = 4.f;
+#ifndef TCL_SPEC_OFF
+#define TCL_SPEC_OFF 3
+#endif
+    constexpr float OFF = TCL_SPEC_OFF;
     unsigned orv = 0;                                 // SPEC: OR of the packed P registers since the last guard test
     static_assert(!SPEC || (FOLD && PV16), "the speculative softmax is the head_dim-40 path");
     auto rebase = [&](const int it, const bool first) __attribute__((always_inline)) {

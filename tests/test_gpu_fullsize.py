@@ -130,6 +130,33 @@ def test_attention_speculative_softmax_guard_and_fallback(L, gain, flagged):
     assert rel(o[:, sp], ref[:, torch.searchsorted(rows, sp)]) < 3e-3
 
 
+@pytest.mark.parametrize("qscale,sink", [(3.0, 0.0), (6.0, 0.0), (1.0, 14.0), (1.0, 18.0)])
+def test_attention_heavy_tail_and_sink_precision(L, qscale, sink):
+    """The speculative softmax keeps P <= 2^-3, i.e. a weight below 2^-21 of its row's maximum vanishes (2^-24 in an f16 flash kernel with
+    P <= 1).  Logit distributions where that band carries mass: heavy tails (q scaled: logit std 4.3 / 8.7 bits) and a sink key 20 / 26 bits
+    above the bulk of its row.  Sampled rows against the f32 reference stay inside half of north_star's 1e-3."""
+    d, B, Tq, Hh = 40, 2, 16400, 8
+    C = Hh * d
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = (torch.randn(B, Tq, C, device="cuda", generator=g) * qscale).to(H)
+    k = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    v = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    if sink:
+        u = torch.randn(C, device="cuda", generator=g)
+        u = (u.view(Hh, d) / u.view(Hh, d).norm(dim=1, keepdim=True)).reshape(C) * (sink * d ** 0.5) ** 0.5
+        q = (q.float() + u).to(H)
+        k[:, 5000] = u.to(H)
+    o = torch.empty_like(q)
+    wq, wkv = ws_bytes(L.tcl_attention_q_bytes(B, Hh, Tq, d)), ws_bytes(L.tcl_attention_kv_bytes(B, Hh, Tq, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tq * C, v, C, Tq * C, o, C, Tq * C, B, Hh, Tq, Tq, d, d ** -0.5, 1, 1, wq, wkv, st())
+    rows = torch.arange(0, Tq, 37, device="cuda")
+    qq = q[:, rows].float().view(B, -1, Hh, d).transpose(1, 2)
+    kk, vv = (t.float().view(B, Tq, Hh, d).transpose(1, 2) for t in (k, v))
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, -1, C)
+    assert torch.isfinite(o).all()
+    assert rel(o[:, rows], ref) < 7e-4
+
+
 @pytest.mark.parametrize("na,nb,C,ratio", [(32400, 10800, 320, 0.6),     # local (random-frame) merge of a 4-frame chunk at level 0
                                            (23760, 23760, 320, 0.5),     # global merge against an equally long bank
                                            (8100, 2700, 640, 0.6),       # level 1

@@ -25,22 +25,15 @@ def chunks_from_draws(flen, chunk_size, rand_first, flip_draw, perm, merge_globa
         chunks = chunks[::-1]
     if not merge_global:
         return chunks
-    n = len(chunks)
-    if chunk_ord == "rand":
-        order = [int(p) for p in perm]
-    elif chunk_ord == "mix":
-        randord = [int(p) for p in perm]
-        rand_len = int(n / perm_div)
-        seqord = sorted(randord[rand_len:])
-        if rand_len > 0:
-            randord = randord[:rand_len]
-            if abs(seqord[-1] - randord[-1]) < abs(seqord[0] - randord[-1]):
-                seqord = seqord[::-1]
-            order = randord + seqord
-        else:
-            order = seqord
-    else:
-        order = list(range(n))
+    order = [int(p) for p in perm] if chunk_ord in ("rand", "mix") else list(range(len(chunks)))
+    if chunk_ord == "mix":
+        # the first len/perm_div draws stay in drawn order; the remaining chunks follow in index order, walked from whichever end lies
+        # nearer (in chunk index) to the last drawn one (generate_utils.py:189-201)
+        head = order[:int(len(order) / perm_div)]
+        tail = sorted(order[len(head):])
+        if head and tail and abs(tail[-1] - head[-1]) < abs(tail[0] - head[-1]):
+            tail.reverse()
+        order = head + tail
     return [chunks[i] for i in order]
 
 

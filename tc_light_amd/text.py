@@ -20,37 +20,34 @@ _ENC = {}
 
 
 def encode_prompt_inner(txt, tokenizer, text_encoder, device):
-    """generate.py:97-114 -> [n_chunks, model_max_length, hidden]."""
-    max_length = tokenizer.model_max_length
-    chunk_length = max_length - 2
-    id_start, id_end = tokenizer.bos_token_id, tokenizer.eos_token_id
-    id_pad = id_end
-
-    def pad(x, p, i):
-        return x[:i] if len(x) >= i else x + [p] * (i - len(x))
-
-    tokens = list(tokenizer(txt, truncation=False, add_special_tokens=False)["input_ids"])
-    chunks = [[id_start] + tokens[i:i + chunk_length] + [id_end] for i in range(0, len(tokens), chunk_length)]
-    if not chunks:
+    """A4 (generate.py:98-114): the untruncated token stream laid out as an id matrix [n_chunks, model_max_length] -- column 0 is BOS, the
+    next model_max_length-2 columns carry the stream row after row, every other cell (the closing column and the ragged end of the
+    last row) is EOS -- and encoded in one batch -> last_hidden_state [n_chunks, model_max_length, hidden]."""
+    width = int(tokenizer.model_max_length)
+    body = width - 2
+    stream = torch.as_tensor(list(tokenizer(txt, truncation=False, add_special_tokens=False)["input_ids"]), dtype=torch.int64)
+    rows = -(-int(stream.numel()) // body)
+    if rows == 0:
         raise ValueError("empty prompt: the reference's chunking yields no chunk to encode (generate.py:108-112)")
-    chunks = [pad(ck, id_pad, max_length) for ck in chunks]
-    token_ids = torch.tensor(chunks).to(device=device, dtype=torch.int64)
+    cells = torch.full((rows * body,), int(tokenizer.eos_token_id), dtype=torch.int64)
+    cells[:stream.numel()] = stream
+    ids = torch.full((rows, width), int(tokenizer.eos_token_id), dtype=torch.int64)
+    ids[:, 0] = int(tokenizer.bos_token_id)
+    ids[:, 1:1 + body] = cells.view(rows, body)
     with torch.no_grad():
-        return text_encoder(token_ids).last_hidden_state
+        return text_encoder(ids.to(device)).last_hidden_state
 
 
 def tile_and_concat(c, uc):
-    """generate.py:121-135: repeat the side with fewer chunks, cut to the longer count, lay the chunks along the sequence.
-    c, uc: [n_chunks, L, D] -> ([1, k*L, D], [1, k*L, D])."""
-    c_len, uc_len = float(len(c)), float(len(uc))
-    max_count = max(c_len, uc_len)
-    c_repeat, uc_repeat = int(math.ceil(max_count / c_len)), int(math.ceil(max_count / uc_len))
-    max_chunk = max(len(c), len(uc))
-    c = torch.cat([c] * c_repeat, dim=0)[:max_chunk]
-    uc = torch.cat([uc] * uc_repeat, dim=0)[:max_chunk]
-    c = torch.cat([p[None, ...] for p in c], dim=1)
-    uc = torch.cat([p[None, ...] for p in uc], dim=1)
-    return c, uc
+    """A4 (generate.py:116-135): both embeddings get the chunk count of the longer prompt -- the shorter one cycles through its chunks --
+    and the chunks become one sequence.  c, uc: [n_chunks, L, D] -> ([1, k*L, D], [1, k*L, D])."""
+    k = max(c.shape[0], uc.shape[0])
+
+    def as_sequence(e):
+        cycled = e.repeat(-(-k // e.shape[0]), 1, 1).narrow(0, 0, k)
+        return cycled.reshape(1, k * e.shape[1], e.shape[2])
+
+    return as_sequence(c), as_sequence(uc)
 
 
 def load_text_encoder(enc_dir, dev):

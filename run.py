@@ -30,6 +30,9 @@ def main(argv=None):
     seed_everything(config.seed)
     if config.sd_version != "iclight":
         raise NotImplementedError("tc_light_amd implements the IC-Light path (sd_version: iclight); see invert.py")
+    if config.generation.prompt is None:          # checked before models, video and flow estimation are paid for
+        raise NotImplementedError("generation.prompt is null: the Cosmos/Pixtral prompt up-sampler (generate.py:538-549) is outside this "
+                                  "engine -- give a prompt (-p ... or generation.prompt)")
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -49,15 +52,30 @@ def main(argv=None):
     frames_all = parser.load_video(frame_ids)
     flows = None
     if config.post_opt.apply_opt:
-        flows = parser.load_flow_cache(frame_ids) if rank == 0 else None
-        if rank == 0 and flows is None:                       # no cache: estimate with MemFlowNet (video_dataparser.py:63-110)
-            from tc_light_amd.memflow import MemFlowEngine
-            from tc_light_amd.model_utils import load_memflow_state
-            flows = parser.estimate_and_cache_flow(frames_all, frame_ids, MemFlowEngine(load_memflow_state(models.get("memflow"), allow=ok_random), dev))
-        if world > 1:                                         # rank 0 owns the cache (read or written); the others receive the tensors
+        # rank 0 owns the flow cache (read, or estimated with MemFlowNet and written: video_dataparser.py:63-110); the other ranks
+        # receive the tensors.  A failure on rank 0 (e.g. missing MemFlow weights) is announced before the payload so that every
+        # rank raises instead of waiting in the broadcast until the collective times out.
+        err = None
+        if rank == 0:
+            try:
+                flows = parser.load_flow_cache(frame_ids)
+                if flows is None:
+                    from tc_light_amd.memflow import MemFlowEngine
+                    from tc_light_amd.model_utils import load_memflow_state
+                    flows = parser.estimate_and_cache_flow(frames_all, frame_ids, MemFlowEngine(load_memflow_state(models.get("memflow"), allow=ok_random), dev))
+            except Exception as e:            # noqa: BLE001 - re-raised below on every rank
+                err = e
+        if world > 1:
+            ok = torch.tensor([0 if err is not None else 1], device=dev)
+            torch.distributed.broadcast(ok, src=0)
+            if int(ok.item()) == 0:
+                torch.distributed.destroy_process_group()
+                raise err if err is not None else RuntimeError("rank 0 failed to load / estimate the optical flow (see its traceback)")
             flows = flows if rank == 0 else tuple(torch.empty(len(frame_ids), 2, parser.h, parser.w, device=dev) for _ in range(2))
             for t in flows:
                 torch.distributed.broadcast(t, src=0)
+        elif err is not None:
+            raise err
     cfg = dict(g); cfg.update(config.post_opt); cfg["seed"] = config.seed
     rmbg = background = None
     if g.get("background_cond"):                               # generate.py:68-69, 147-167
@@ -68,9 +86,6 @@ def main(argv=None):
         if background.shape[0] == len(frame_ids) and world > 1:     # a per-frame background video: this rank's block of it
             background = background[lo:hi]
     gen = Generator(pipe.unet, pipe.vae, cfg, dist=d, scheduler=scheduler, rmbg=rmbg)
-    if g.prompt is None:
-        raise NotImplementedError("generation.prompt is null: the Cosmos/Pixtral prompt up-sampler (generate.py:538-549) is outside this "
-                                  "engine -- give a prompt (-p ... or generation.prompt)")
     for name, prompt in g.prompt.items():
         conds = encode_prompt_pair(prompt, g.negative_prompt, dev, models.get("text_encoder"), allow_random=ok_random)
         conds_t = encode_prompt_pair(g.prompt_t, g.negative_prompt_t, dev, models.get("text_encoder"), allow_random=ok_random)
@@ -88,15 +103,15 @@ def main(argv=None):
             path = os.path.join(g.output_path, f"lmr_{g.local_merge_ratio}_gmr_{g.global_merge_ratio}_alpha_t_{g.alpha_t}_opt_{name}")
             save_config(config, path, gene=True)
             out = out.clamp(0, 1)
-            save_video(out, path, save_frame=bool(g.get("save_frame", False)), fps=parser.fps, gif=False)
-            np.save(os.path.join(path, "output.npy"), (out * 255).byte().permute(0, 2, 3, 1).cpu().numpy())
-            gt_path = os.path.join(path, "gt")
-            if not os.path.exists(gt_path) or len(os.listdir(gt_path)) != len(frame_ids):
-                save_video(frames_all, path, save_frame=False, post_fix="_gt", fps=parser.fps, gif=False)
+            np.save(os.path.join(path, "output.npy"), (out * 255).byte().permute(0, 2, 3, 1).cpu().numpy())    # first: survives any encoder failure
             if config.post_opt.apply_opt:
                 save_loss_curve(info["losses_exposure"], path, "loss_exposure")
                 if info["losses_unique"] is not None:
                     save_loss_curve(info["losses_unique"], path, "loss_unique_tensor")
+            save_video(out, path, save_frame=bool(g.get("save_frame", False)), fps=parser.fps, gif=False)
+            gt_path = os.path.join(path, "gt")
+            if not os.path.exists(gt_path) or len(os.listdir(gt_path)) != len(frame_ids):
+                save_video(frames_all, path, save_frame=False, post_fix="_gt", fps=parser.fps, gif=False)
             print(f"[INFO] {len(frame_ids)} frames in {info['total_time']:.1f} s ({1 / config.sec_per_frame:.3f} frames/s) -> {path}")
     if world > 1:
         torch.distributed.destroy_process_group()

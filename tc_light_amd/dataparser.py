@@ -123,35 +123,47 @@ def save_video(frames, path, frame_ids=None, save_frame=False, gif=True, post_fi
     frames = frames[ids]
     proc = (frames.permute(0, 2, 3, 1) * 255).to(torch.uint8).cpu()
     out = None
-    if not gif:
+
+    def _mp4_torchvision(dst):
+        from torchvision.io import write_video
+        write_video(dst, proc, fps=fps, video_codec="libx264", options={"crf": "23", "preset": "medium"})
+
+    def _mp4_cv2(dst):
+        import cv2
+        wr = cv2.VideoWriter(dst, cv2.VideoWriter_fourcc(*"mp4v"), fps, (proc.shape[2], proc.shape[1]))
+        if not wr.isOpened():
+            raise RuntimeError("cv2.VideoWriter could not open the output")
+        for fr in proc.numpy():
+            wr.write(fr[..., ::-1])
+        wr.release()
+
+    def _gif_imageio(dst):
+        import imageio
+        imageio.mimsave(dst, [f.numpy() for f in proc], "GIF", fps=fps, loop=0)
+
+    def _gif_pil(dst):
+        from PIL import Image
+        ims = [Image.fromarray(f.numpy()) for f in proc]
+        ims[0].save(dst, save_all=True, append_images=ims[1:], duration=int(1000 / max(fps, 1)), loop=0)
+
+    # an encoder that is missing OR fails (a torchvision / PyAV build without libx264, a cv2 writer error) must not lose a finished
+    # relight: every failure falls through to the next writer and finally to .npy + PNG frames
+    dst = os.path.join(path, f"output{post_fix}.gif" if gif else f"output{post_fix}.mp4")
+    for writer in ((_gif_imageio, _gif_pil) if gif else (_mp4_torchvision, _mp4_cv2)):
         try:
-            from torchvision.io import write_video
-            out = os.path.join(path, f"output{post_fix}.mp4")
-            write_video(out, proc, fps=fps, video_codec="libx264", options={"crf": "23", "preset": "medium"})
-        except ImportError:
-            try:
-                import cv2
-                out = os.path.join(path, f"output{post_fix}.mp4")
-                wr = cv2.VideoWriter(out, cv2.VideoWriter_fourcc(*"mp4v"), fps, (proc.shape[2], proc.shape[1]))
-                for fr in proc.numpy():
-                    wr.write(fr[..., ::-1])
-                wr.release()
-            except ImportError:
-                out = None
-    else:
-        out = os.path.join(path, f"output{post_fix}.gif")
-        try:
-            import imageio
-            imageio.mimsave(out, [f.numpy() for f in proc], "GIF", fps=fps, loop=0)
-        except ImportError:
-            from PIL import Image
-            ims = [Image.fromarray(f.numpy()) for f in proc]
-            ims[0].save(out, save_all=True, append_images=ims[1:], duration=int(1000 / max(fps, 1)), loop=0)
+            writer(dst)
+            out = dst
+            break
+        except Exception as e:            # noqa: BLE001 - any encoder failure
+            if not isinstance(e, ImportError):
+                print(f"[WARN] {writer.__name__[1:]} failed ({type(e).__name__}: {e}); trying the next writer")
+            if os.path.exists(dst):
+                os.remove(dst)
     if out is None:                                    # no encoder in this image: keep the data, say so
         out = os.path.join(path, f"output{post_fix}.npy")
         np.save(out, proc.numpy())
         save_frames(frames, os.path.join(path, f"frames{post_fix}"), frame_ids=ids)
-        print(f"[INFO] no video encoder (torchvision / cv2): wrote {out} and PNG frames instead of output{post_fix}.mp4")
+        print(f"[INFO] no working video encoder (torchvision / cv2 / imageio): wrote {out} and PNG frames instead of output{post_fix}.mp4")
     else:
         print(f"[INFO] save video to {out}")
     if save_frame:

@@ -96,7 +96,7 @@ def _worker(rank, world, port, ret):
     out, feat, l2 = P.unique_tensor_optimization(ds2, inv.cuda(), s2, batch_size=4, k=k, dist=pd)   # rounding-noise driven
     torch.cuda.synchronize()
     if rank == 0:
-        ret.put(tuple(t.cpu() for t in (expo, l1, out, feat, l2)))
+        ret.put(tuple(t.detach().cpu().numpy() for t in (expo, l1, out, feat, l2)))      # numpy: no fd-sharing race with the exiting worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -110,7 +110,7 @@ def test_two_process_global_stages_equal_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    expo, l1, out, feat, l2 = ret.get()
+    expo, l1, out, feat, l2 = (torch.from_numpy(a) for a in ret.get())
     for p in procs:
         p.join(300)
         assert p.exitcode == 0

@@ -2,6 +2,8 @@
 import os
 import socket
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -59,7 +61,7 @@ def _worker(rank, world, port, n_total, ret):
     nt = sharded_temporal_pass(d, x[lo:hi].clone(), cc_full, n_total, _items(n_total, 10), _compute)
     full = d.gather_frames(nt, n_total)
     if rank == 0:
-        ret.put(full)
+        ret.put(full.numpy())            # numpy, not torch tensors: fd-shared tensors need the producer alive until the parent unpickles
     assert d.max_float(float(rank), "cpu") == world - 1
     dist.destroy_process_group()
 
@@ -72,7 +74,7 @@ def test_sharded_temporal_pass_world2():
         procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, ret)) for r in range(2)]
         for p in procs:
             p.start()
-        got = ret.get()
+        got = torch.from_numpy(ret.get())
         for p in procs:
             p.join(60)
             assert p.exitcode == 0
@@ -183,7 +185,7 @@ def _stage_worker(rank, world, port, ret):
         _adam(p, g, m, v, lr, 1e-15, it + 1)
     l2 = distributed_adam_loop(d, sched, flat, torch.zeros(npad), grad2, adam2, shard_state=True)
     if rank == 0:
-        ret.put((expo, l1, flat[:3 * k].view(k, 3).clone(), l2))
+        ret.put(tuple(np.asarray(t.detach().cpu().numpy()) for t in (expo, l1, flat[:3 * k].view(k, 3).clone(), l2)))
     dist.destroy_process_group()
 
 
@@ -195,7 +197,7 @@ def test_global_stage1_stage2_world2_equals_single_process():
     procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    expo, l1, feats, l2 = ret.get()
+    expo, l1, feats, l2 = (torch.from_numpy(a) for a in ret.get())
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

@@ -29,6 +29,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page8[64];
+#ifdef G8_PROF
+__device__ unsigned long long* g8_prof_buf;
+#endif
+#ifndef G8_ABL
+#define G8_ABL 0      // lab-only knock-outs of k_gemm8p: 1 = no DMA in the K loop, 2 = no fragment reads in the K loop (results are garbage)
+#endif
 
 template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const _Float16* __restrict__ A, c
 //        earliest piece of stage t+3 is issued in G0's L(t) = I(2t).
 //   RAW  every wave passes W(t+1) ("my pieces of stage t+1 have landed") before b_2t+2; the first read of stage t+1 is G0's L(t+1)
 //        = I(2t+2).  W0 runs after D(t+3): up to two whole stages stay in flight; W1 runs before it: stage t+2 and the NL early pieces.
-template <int MT, int NT, int WM, int WN, bool CONV, int NL>
+template <int MT, int NT, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(512) void k_gemm8s(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const _Float16* __restrict__ bias,
                                                 const _Float16* __restrict__ resid, _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw,
                                                 int ldc, int ldr, int act, ConvP cp, int tiles_m, int tiles_n) {
@@ -257,8 +263,9 @@ __global__ __launch_bounds__(512) void k_gemm8s(const _Float16* __restrict__ A, 
     constexpr int NP = (A_P + B_P + 7) / 8;
     constexpr int NPA = A_P / 8, NPB = NP - NPA;
     constexpr int STAGE = (A_P + B_P) * 1024;
+    constexpr int NL = 0;                                  // pieces of a stage still issued in the read segment (measured: 0 is best)
     constexpr int nM = 2 * MT * NT, PM = NP - NL, G = nM / (PM > 0 ? PM : 1);
-    static_assert(A_P % 8 == 0 && NL >= 0 && NL <= NP && G >= 1, "tile / schedule");
+    static_assert(A_P % 8 == 0 && G >= 1, "tile / schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
@@ -338,16 +345,26 @@ __global__ __launch_bounds__(512) void k_gemm8s(const _Float16* __restrict__ A, 
             _Pragma("unroll") for (int b = 0; b < NT; ++b) { int R = b * 32 + frow; fb[ks][b] = *(const half8*)(bb_ + R * ROWB + (((2 * ks + fh) ^ ((R >> 2) & 3)) << 4)); } \
         }                                                                                                                     \
     }
+    // fragments of K substep KS (0 | 1) of stage KT only
+#define G8S_READK(KT, KS)                                                                                                     \
+    {                                                                                                                         \
+        const char* ab_ = smem + ((KT) % NS) * STAGE + (wm * MT * 32) * ROWB;                                                 \
+        const char* bb_ = smem + ((KT) % NS) * STAGE + BM * ROWB + (wn * NT * 32) * ROWB;                                     \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) { int R = a * 32 + frow; fa[KS][a] = *(const half8*)(ab_ + R * ROWB + (((2 * (KS) + fh) ^ ((R >> 2) & 3)) << 4)); } \
+        _Pragma("unroll") for (int b = 0; b < NT; ++b) { int R = b * 32 + frow; fb[KS][b] = *(const half8*)(bb_ + R * ROWB + (((2 * (KS) + fh) ^ ((R >> 2) & 3)) << 4)); } \
+    }
     // M(t) with the PM late pieces of stage KT pinned between the MFMAs: piece NL + q right after MFMA q * G
-#define G8S_MSEG(KT)                                                                                                          \
+#define G8S_MSEG(KT) G8S_MRANGE(KT, 0, nM)
+#define G8S_MRANGE(KT, LO, HI) G8S_MRANGEF(KT, LO, HI, 0)
+#define G8S_MRANGEF(KT, LO, HI, FOFF)                                                                                                 \
     {                                                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                                        \
-        _Pragma("unroll") for (int mi = 0; mi < nM; ++mi) {                                                                  \
+        _Pragma("unroll") for (int mi = (LO); mi < (HI); ++mi) {                                                             \
             const int ks_ = mi / (MT * NT), a_ = (mi / NT) % MT, b_ = mi % NT;                                                \
             acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks_][a_], fb[ks_][b_], acc[a_][b_], 0, 0, 0);            \
-            if (PM > 0 && mi % G == 0 && mi / G < PM) {                                                                       \
+            if (PM > 0 && ((mi + (FOFF)) % nM) % G == 0 && ((mi + (FOFF)) % nM) / G < PM) {                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                                                            \
-                G8S_FIRE(KT, NL + mi / G);                                                                                    \
+                G8S_FIRE(KT, NL + ((mi + (FOFF)) % nM) / G);                                                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                                            \
             }                                                                                                                 \
         }                                                                                                                     \
@@ -367,50 +384,279 @@ __global__ __launch_bounds__(512) void k_gemm8s(const _Float16* __restrict__ A, 
         for (int i = 0; i < NP; ++i) G8S_FIRE(s, i);
     }
     wait_vm<2 * NP>();                                  // W(0)
+#ifdef G8_PROF      // lab only (tools/micro/gemm8_lab.hip): shader cycles per segment, summed over the K loop, for wave 0 / wave 4 of each block
+    unsigned long long tsum_[5] = {0, 0, 0, 0, 0}, tlast_, tnow_;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast_));
+#define G8S_T(I) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tnow_) :: "memory"); tsum_[I] += tnow_ - tlast_; tlast_ = tnow_; }
+#else
+#define G8S_T(I)
+#endif
     if (grp == 0) {
         for (int t = 0; t < nk; ++t) {
             __builtin_amdgcn_s_barrier();
+            G8S_T(0)
             G8S_READ(t);
             G8S_PREP(t + PD);
 #pragma unroll
             for (int i = 0; i < NL; ++i) G8S_FIRE(t + PD, i);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G8S_T(1)
             __builtin_amdgcn_s_barrier();
+            G8S_T(2)
             G8S_MSEG(t + PD);
+            G8S_T(3)
             G8S_WAIT0();
+            G8S_T(4)
         }
         __builtin_amdgcn_s_barrier();
     } else {
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t) {
             __builtin_amdgcn_s_barrier();
+            G8S_T(0)
             G8S_READ(t);
             G8S_PREP(t + PD);
 #pragma unroll
             for (int i = 0; i < NL; ++i) G8S_FIRE(t + PD, i);
-            G8S_WAIT1();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G8S_T(1)
+            G8S_WAIT1();
+            G8S_T(4)
             __builtin_amdgcn_s_barrier();
+            G8S_T(2)
             G8S_MSEG(t + PD);
+            G8S_T(3)
         }
     }
+#ifdef G8_PROF
+    if (g8_prof_buf && lane == 0 && (wid & 3) == 0 && blockIdx.x < 64) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g8_prof_buf[(blockIdx.x * 2 + grp) * 5 + i] = tsum_[i];
+    }
+#endif
+#undef G8S_T
     wait_vm<0>();                                       // dummy pieces of the last steps (dump area) before the epilogue reuses the LDS
 #undef G8S_GLDS
 #undef G8S_PREP
 #undef G8S_FIRE
 #undef G8S_READ
+#undef G8S_READK
+#undef G8S_MRANGE
+#undef G8S_MRANGEF
 #undef G8S_MSEG
 #undef G8S_WAIT0
 #undef G8S_WAIT1
     g8_epilogue<MT, NT, WM, WN>(acc, smem, bias, resid, C, M, N, ldc, ldr, act, m0, n0, wid, lane, wm, wn);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Schedule 5 (k_gemm8p, round 3): software-pipelined half steps, ONE block barrier per K step, buffer-addressed LDS-DMA.  Same tiles,
+// ring, swizzle, K order and epilogue as k_gemm8 (bit-identical results).
+//
+// Why (segment timers of tools/micro/gemm8_lab.hip on k_gemm8s, 256 x 320 tile, cycles per K step of 32): the two-barrier ping-pong
+// spends 2 x (640 MFMA + 5 x 50 DMA issue) in the two MFMA segments plus 110-170 idle cycles per barrier hand-over, and the LDS-read +
+// address segment (350 dense, 900-1100 conv) of one group has to fit under the other group's MFMA segment: 2 200-2 300 cycles against
+// 1 280 of matrix work.  Here a wave never stops issuing MFMAs for its reads:
+//   half step h = 2t + ks: the MT NT MFMAs of K substep ks of stage t run while the fragments of half step h + 1 are read into the
+//   OTHER register half (free since half step h - 1) and the DMA pieces of stage t + 3 go out between the MFMAs.
+//   B_t = "every wave has waited for its pieces of stage t + 1 and retired its reads of stage t - 1".  Group 0 passes B_t before half
+//   step 2t, group 1 before half step 2t - 1: the groups stay half a step apart, so the two waves of a SIMD interleave their MFMA
+//   streams freely instead of alternating through barrier hand-overs.
+//   RAW  G0 reads stage t (ks 1) and stage t+1 (ks 0) after B_t; G1 reads stage t (ks 0, ks 1) after B_t: all covered by "stage t + 1
+//        landed at B_t".  W = vmcnt(NP) right before a wave's barrier: only the stage it has just issued stays in flight.
+//   WAR  stage t+3 -> ring slot of stage t-1, issued after B_t by both groups (G0: half steps 2t, 2t+1; G1: 2t-1, 2t).  Reads of stage
+//        t-1 end in half step 2t-2 for both groups and are retired (lgkmcnt 0) before the wave's next barrier, which is B_t or earlier.
+// Addressing: a DMA piece is `buffer_load_dwordx4 ... offen lds` through one resource descriptor per operand; the per-lane part of the
+// address is ONE 32-bit byte offset fixed for the whole K loop (row of the piece + swizzled 16-B chunk), the K step adds a scalar.
+//   * padding needs no zero page: offset 0xffffffff is outside the descriptor's range and the hardware returns zeros.  Rows past M / N are
+//     clamped to the last row instead (their outputs are never stored);
+//   * implicit 3x3 convolution (stride 1 | 2, no up-sampling): per lane and piece the base offset of output pixel (oy, ox) and a 9-bit
+//     validity mask of its taps, computed once; per stage the tap / channel-slice offset is a scalar: 3 vector instructions per A piece
+//     and stage instead of ~25 (k_gemm8s: iy / ix / bounds / 64-bit address per piece), and no per-stage pointer table in registers.
+// Requires operands addressable with 32 bits (host: bytes < 4 GiB, else the k_gemm8s path; up-sampling convolutions take k_gemm8s too).
+template <int MT, int NT, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const _Float16* __restrict__ bias,
+                                                const _Float16* __restrict__ resid, _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw,
+                                                int ldc, int ldr, int act, ConvP cp, int tiles_m, int tiles_n, unsigned a_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in the device pass only; the host pass needs just the stub
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32, KB = 32, ROWB = 64;
+    constexpr int NS = 4, PD = 3;
+    constexpr int A_P = BM / 16, B_P = BN / 16;
+    constexpr int NP = (A_P + B_P + 7) / 8;
+    constexpr int NPA = A_P / 8, NPB = NP - NPA;
+    constexpr int STAGE = (A_P + B_P) * 1024;
+    constexpr int nM = 2 * MT * NT, HALF = MT * NT, G = nM / NP;
+    static_assert(A_P % 8 == 0 && G >= 1, "tile / schedule");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tn = j % tiles_n, tm = (j / tiles_n) * 8 + xcd;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2;
+    const int wm = wid % WM, wn = wid / WM;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
+    const int rr = lane >> 2, csrc = ((lane & 3) ^ ((rr >> 2) & 3)) * 16;         // source chunk (bytes) of this lane's LDS chunk
+    unsigned aoff[NPA], amask[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + (wid + 8 * i) * 16 + rr;
+        if (!CONV) { aoff[i] = (unsigned)min(m, M - 1) * (unsigned)lda * 2u + csrc; amask[i] = 0; }
+        else {
+            const int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
+            const int iy0 = oy * cp.stride - cp.pad, ix0 = ox * cp.stride - cp.pad;
+            aoff[i] = (unsigned)(((b * cp.Hin + iy0) * cp.Win + ix0) * cp.Cin) * 2u + csrc;      // wraps for border pixels; only used with a valid tap
+            unsigned mk = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = iy0 + tap / 3, ix = ix0 + tap % 3;
+                if (m < M && iy >= 0 && iy < cp.Hin && ix >= 0 && ix < cp.Win) mk |= 1u << tap;
+            }
+            amask[i] = mk;
+        }
+    }
+    unsigned woff[NPB]; int wdst[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int q = wid + 8 * (i + NPA), n = n0 + (q - A_P) * 16 + rr;
+        const bool real = q < A_P + B_P;
+        woff[i] = (unsigned)min(real ? n : n0, N - 1) * (unsigned)ldw * 2u + csrc;
+        wdst[i] = real ? q * 1024 : -1;
+    }
+    const int nk = K / KB;
+    // piece I of stage KT (KT >= nk: a dummy that re-reads the last stage into the dump area, so that every wave issues NP pieces per stage)
+#define G8P_FIRE(KT, I)                                                                                                       \
+    {                                                                                                                         \
+        const int kt_ = min((KT), nk - 1);                                                                                    \
+        char* sb_ = smem + ((KT) % NS) * STAGE;                                                                               \
+        char* dump_ = smem + NS * STAGE;                                                                                      \
+        int ka_ = kt_ * KB, kw_ = ka_, tap_ = 0;                                                                              \
+        if (CONV) { int c0_; tap_ = conv_kmap(ka_, cp.Cin, c0_); kw_ = tap_ * cp.Cin + c0_; ka_ = ((tap_ / 3) * cp.Win + tap_ % 3) * cp.Cin + c0_; } \
+        if ((I) < NPA) {                                                                                                      \
+            unsigned vo_ = aoff[(I) < NPA ? (I) : 0] + (unsigned)ka_ * 2u;                                                    \
+            if (CONV) vo_ = ((amask[(I) < NPA ? (I) : 0] >> tap_) & 1u) ? vo_ : 0xffffffffu;                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)((KT) < nk ? sb_ + (wid + 8 * (I)) * 1024 : dump_), 16, vo_, 0, 0, 0); \
+        } else {                                                                                                              \
+            const int iw_ = (I) >= NPA ? (I) - NPA : 0;                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(((KT) < nk && wdst[iw_] >= 0) ? sb_ + wdst[iw_] : dump_), 16, woff[iw_] + (unsigned)kw_ * 2u, 0, 0, 0); \
+        }                                                                                                                     \
+    }
+
+    float16v acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    half8 fa[2][MT], fb[2][NT];
+#define G8P_READK(KT, KS)                                                                                                     \
+    {                                                                                                                         \
+        const char* ab_ = smem + ((KT) % NS) * STAGE + (wm * MT * 32) * ROWB;                                                 \
+        const char* bb_ = smem + ((KT) % NS) * STAGE + BM * ROWB + (wn * NT * 32) * ROWB;                                     \
+        _Pragma("unroll") for (int a = 0; a < MT; ++a) { int R = a * 32 + frow; fa[KS][a] = *(const half8*)(ab_ + R * ROWB + (((2 * (KS) + fh) ^ ((R >> 2) & 3)) << 4)); } \
+        _Pragma("unroll") for (int b = 0; b < NT; ++b) { int R = b * 32 + frow; fb[KS][b] = *(const half8*)(bb_ + R * ROWB + (((2 * (KS) + fh) ^ ((R >> 2) & 3)) << 4)); } \
+    }
+    // the MFMAs [LO, HI) of a step with the pieces of stage KT pinned between them: piece q right after MFMA index q * G of the FIRING order,
+    // which is the MFMA order rotated by FOFF (group 1 issues the second part of a stage before the first part of the next one)
+#define G8P_MRANGE(KT, LO, HI, FOFF)                                                                                          \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int mi = (LO); mi < (HI); ++mi) {                                                             \
+            const int ks_ = mi / (MT * NT), a_ = (mi / NT) % MT, b_ = mi % NT;                                                \
+            acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks_][a_], fb[ks_][b_], acc[a_][b_], 0, 0, 0);            \
+            if (!(G8_ABL & 1) && ((mi + (FOFF)) % nM) % G == 0 && ((mi + (FOFF)) % nM) / G < NP) {                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                            \
+                G8P_FIRE(KT, ((mi + (FOFF)) % nM) / G);                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+#ifdef G8_PROF
+    unsigned long long tsum_[5] = {0, 0, 0, 0, 0}, tlast_, tnow_;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast_));
+#define G8P_T(I) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tnow_) :: "memory"); tsum_[I] += tnow_ - tlast_; tlast_ = tnow_; }
+#else
+#define G8P_T(I)
+#endif
+
+    // prologue: stages 0 .. 2 whole; stages 0 and 1 landed before the first reads (B_0 certifies stage 1)
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) G8P_FIRE(s, i);
+    }
+    wait_vm<NP>();
+    __builtin_amdgcn_s_barrier();
+    G8P_READK(0, 0);
+    if (G8_ABL & 2) G8P_READK(0, 1);
+#define G8P_READL(KT, KS) { if (!(G8_ABL & 2)) G8P_READK(KT, KS); }
+    if (grp == 0) {
+        for (int t = 0; t < nk; ++t) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // B_t
+            G8P_T(0)
+            G8P_READL(t, 1);
+            G8P_MRANGE(t + PD, 0, HALF, 0);
+            G8P_T(1)
+            G8P_READL(t + 1, 0);
+            G8P_MRANGE(t + PD, HALF, nM, 0);
+            G8P_T(3)
+            wait_vm<NP>();
+            G8P_T(4)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (q * G < HALF) G8P_FIRE(PD, q);          // the "half step -1" part of stage 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // B_0
+        for (int t = 0; t < nk; ++t) {
+            G8P_READL(t, 1);
+            G8P_MRANGE(t + PD, 0, HALF, HALF);          // second part of stage t+3
+            G8P_T(1)
+            wait_vm<NP>();
+            G8P_T(4)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // B_t+1
+            G8P_T(0)
+            G8P_READL(t + 1, 0);
+            G8P_MRANGE(t + 1 + PD, HALF, nM, HALF);     // first part of stage t+4
+            G8P_T(3)
+        }
+    }
+#ifdef G8_PROF
+    if (g8_prof_buf && lane == 0 && (wid & 3) == 0 && blockIdx.x < 64) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g8_prof_buf[(blockIdx.x * 2 + grp) * 5 + i] = tsum_[i];
+    }
+#endif
+    wait_vm<0>();                                       // dummy pieces (dump area) and group 1's early part of a stage past the end
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last half step's look-ahead reads (unused) before the epilogue rewrites the LDS
+#undef G8P_FIRE
+#undef G8P_READK
+#undef G8P_READL
+#undef G8P_MRANGE
+#undef G8P_T
+    g8_epilogue<MT, NT, WM, WN>(acc, smem, bias, resid, C, M, N, ldc, ldr, act, m0, n0, wid, lane, wm, wn);
+#endif
+}
+
 #ifndef G8_LAB_ONLY   // tools/micro/gemm8_lab.hip instantiates single kernels itself
-// schedule: 0 = k_gemm8 (round-2 ping-pong, DMA in the LDS-read segment), 1 = k_gemm8s with every piece in the MFMA segment, 2 = k_gemm8s with
-// the first two pieces of a stage still in the read segment.  TCL_GEMM8_SCHED overrides the default (experiments; results are bit-identical).
+// schedule: 0 = k_gemm8 (round-2 ping-pong, DMA in the LDS-read segment), 1 = k_gemm8s (two barriers, DMA in the MFMA segment), 2 = k_gemm8p
+// (half-step pipeline, one barrier per step, buffer-addressed DMA; default).  TCL_GEMM8_SCHED overrides it (experiments; bit-identical results).
+// Measured on the metric's shapes (tools/micro/gemm8_lab.hip, profiles/r3_gemm8_lab.txt): dense K >= 640 +17...33 %, 3x3 convs +6...10 % over
+// schedule 0; variants that lost and are not in the tree: two early pieces in the read segment (-4 %), static / alternating s_setprio
+// (+-1 %), a 24-cycle stagger of the four SIMDs behind each barrier (-8 %).
 int g_gemm8_sched = -1;
 static int gemm8_sched() {
-    if (g_gemm8_sched < 0) { const char* e = getenv("TCL_GEMM8_SCHED"); g_gemm8_sched = e ? atoi(e) : 1; }
+    if (g_gemm8_sched < 0) { const char* e = getenv("TCL_GEMM8_SCHED"); g_gemm8_sched = e ? atoi(e) : 2; }
     return g_gemm8_sched;
 }
 
@@ -424,17 +670,21 @@ static int launch8(const _Float16* A, const _Float16* W, const _Float16* bias, c
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k_gemm8<MT, NT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8s<MT, NT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8p<MT, NT, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8p<MT, NT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const dim3 grid(cdiv(tm, 8) * 8 * tn);
-    const int sched = gemm8_sched();
-#define G8_LAUNCH(KERN) hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn)
-    if (sched == 1) { if (cp.conv) G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, true, 0>)); else G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, false, 0>)); }
-    else if (sched == 2) { if (cp.conv) G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, true, 2>)); else G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, false, 2>)); }
+    int sched = gemm8_sched();
+    // k_gemm8p addresses its operands with 32-bit offsets and has no nearest-upsample gather: those calls take k_gemm8s
+    const size_t a_bytes = cp.conv ? (size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 : ((size_t)(M - 1) * lda + K) * 2;
+    const size_t w_bytes = ((size_t)(N - 1) * ldw + K) * 2;
+    if (sched == 2 && (a_bytes >= 0xffffff00ull || w_bytes >= 0xffffff00ull || (cp.conv && (cp.Hup != cp.Hin || cp.Wup != cp.Win)))) sched = 1;
+#define G8_LAUNCH(KERN, ...) hipLaunchKernelGGL((KERN), grid, dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, ##__VA_ARGS__)
+    if (sched == 2) { if (cp.conv) G8_LAUNCH((k_gemm8p<MT, NT, WM, WN, true>), (unsigned)a_bytes, (unsigned)w_bytes); else G8_LAUNCH((k_gemm8p<MT, NT, WM, WN, false>), (unsigned)a_bytes, (unsigned)w_bytes); }
+    else if (sched == 1) { if (cp.conv) G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, true>)); else G8_LAUNCH((k_gemm8s<MT, NT, WM, WN, false>)); }
     else { if (cp.conv) G8_LAUNCH((k_gemm8<MT, NT, WM, WN, true>)); else G8_LAUNCH((k_gemm8<MT, NT, WM, WN, false>)); }
 #undef G8_LAUNCH
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;

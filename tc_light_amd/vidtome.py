@@ -23,8 +23,8 @@ I32 = torch.int32
 class VidToMe:
     def __init__(self, device, local_merge_ratio=0.6, merge_global=True, global_merge_ratio=0.5, max_downsample=2, seed=123,
                  batch_size=2, align_batch=True, target_stride=4, global_rand=0.5, enabled=True):
-        if batch_size != 2 or not align_batch:
-            raise NotImplementedError("TC-Light runs VidToMe with batch_size=2 (uncond, cond) and align_batch=True")
+        if batch_size != 2:
+            raise NotImplementedError("TC-Light runs VidToMe with batch_size=2 (uncond, cond)")
         self.dev = torch.device(device)
         self.args = dict(local_merge_ratio=local_merge_ratio, merge_global=merge_global, global_merge_ratio=global_merge_ratio,
                          max_downsample=max_downsample, seed=seed, batch_size=batch_size, align_batch=align_batch,
@@ -34,7 +34,7 @@ class VidToMe:
         self.banks = {}                 # block name -> [2, Tb, C] f16 (module.global_tokens, patch.py:60-82)
         self._pos = {}
         self._ws = None
-        self.draws = None               # optional injected (randf, coin) for the next forwards (parity tests)
+        self.draws = None               # optional injected (randf, coin) for the next forwards (parity tests); randf: int or one per round
         self.trace = None               # set to a list to record per-block maps (parity tests)
         self.L = lib()
 
@@ -47,33 +47,50 @@ class VidToMe:
         self.begin_step([F], size)
         self.select_chunk(0)
 
+    def round_frames(self, F, randfs=None):
+        """Frame counts of the randframe rounds of an F-frame chunk (patch.py:43-56): the dst set of a round is every frame f with
+        f % min(target_stride, frames) == randf, and those frames are what the next round sees -- 4 -> [4], 8 -> [8, 2], 16 -> [16, 4].
+        Draws one randf per round (or checks the given ones) -> (frame counts, randfs)."""
+        counts, out, cur, k = [], [], F, 0
+        while cur > 1:
+            ts = min(self.args["target_stride"], cur)
+            rf = int(randfs[k]) if randfs is not None else int(self.rng.integers(0, ts))
+            counts.append(cur); out.append(rf)
+            cur = sum(1 for f in range(cur) if f % ts == rf)
+            k += 1
+        return counts, out
+
     def begin_step(self, Fs, size):
-        """One UNet pass over the chunks Fs (reference chunk order): draw each chunk's (randf, coin) in that order."""
+        """One UNet pass over the chunks Fs (reference chunk order): draw each chunk's (randf per round, coin) in that order."""
         self.size = size
         self._chunks = []
         for F in Fs:
             if self.draws is not None:
                 randf, coin = self.draws.pop(0)
+                randfs = self.round_frames(F, list(randf) if isinstance(randf, (list, tuple)) else [randf])[1]
             else:
-                ts = min(self.args["target_stride"], F)
-                randf = int(self.rng.integers(0, ts)) if F > 1 else -1
+                randfs = self.round_frames(F)[1]
                 coin = float(self.rng.random())
-            self._chunks.append((F, randf, coin))
+            self._chunks.append((F, randfs, coin))
 
     def select_chunk(self, i):
-        self.F, self.randf, self.coin = self._chunks[i]
+        self.F, self.randfs, self.coin = self._chunks[i]
+        self.randf = self.randfs[0] if self.randfs else -1
 
     def end_forward(self):
         pass
 
     # ---- helpers
-    def _positions(self, F, N, randf):
-        key = (F, N, randf)
+    def _positions(self, F, N, randf, unm_pre=0):
+        """merge.py:44-67: the sequence is [unm_pre | F frames of N tokens]; src = the tokens of the frames f with f % min(stride, F) != randf,
+        dst = the other frames' tokens followed by the unm_pre leading tokens."""
+        key = (F, N, randf, unm_pre)
         hit = self._pos.get(key)
         if hit is None:
             idx = torch.arange(F * N, dtype=I32)
-            dst = (idx // N) % min(self.args["target_stride"], F) == randf     # merge.py:59-60 (unm_pre = 0)
-            hit = self._pos[key] = (idx[~dst].contiguous().to(self.dev), idx[dst].contiguous().to(self.dev))
+            dst = (idx // N) % min(self.args["target_stride"], F) == randf
+            b = torch.cat([idx[dst] + unm_pre, torch.arange(unm_pre, dtype=I32)])
+            hit = self._pos[key] = ((idx[~dst] + unm_pre).contiguous().to(self.dev), b.contiguous().to(self.dev))
         return hit
 
     def _range(self, lo, hi):
@@ -83,10 +100,46 @@ class VidToMe:
             hit = self._pos[key] = torch.arange(lo, hi, dtype=I32, device=self.dev)
         return hit
 
+    # Maps are int32 tensors: 1-D when the two batch entries share the matching (align_batch, merge.py:93-108), [2, n] when every entry has
+    # its own (merge.py:109-118).  The three helpers below hide the difference from compute_merge.
+    def _gather(self, s1, bs1, mp, out, bso, n, C):
+        L = self.L
+        if mp is None or mp.dim() == 1:
+            L.tcl_gather_rows_f16(s1, bs1, 0, 0, mp if mp is not None else 0, out, bso, 2, n, C, stream())
+        else:
+            f1, fo = s1.reshape(-1), out.reshape(-1)
+            for b in range(2):
+                L.tcl_gather_rows_f16(f1[b * bs1:], bs1, 0, 0, mp[b], fo[b * bso:], bso, 1, n, C, stream())
+
+    def _compose(self, outer, inner, off, n):
+        """out[i] = outer[off + inner[i]] (inner None = identity), per batch entry when either map is."""
+        L = self.L
+        per = outer.dim() == 2 or (inner is not None and inner.dim() == 2)
+        if not per:
+            out = torch.empty(n, dtype=I32, device=self.dev)
+            L.tcl_index_compose(outer, inner if inner is not None else 0, off, n, out, stream())
+            return out
+        out = torch.empty(2, n, dtype=I32, device=self.dev)
+        for b in range(2):
+            L.tcl_index_compose(outer[b] if outer.dim() == 2 else outer, (inner[b] if inner.dim() == 2 else inner) if inner is not None else 0,
+                                off, n, out[b], stream())
+        return out
+
+    def unmerge_add(self, h, bsh, y, T, unm, n, C):
+        """h[b][i] += y[b][unm[i]]: unmerge of attn1's output + residual (patch.py:178-179); unm None = identity."""
+        L = self.L
+        if unm is None or unm.dim() == 1:
+            L.tcl_gather_add_rows_f16(h, bsh, y, T * C, unm if unm is not None else 0, 2, n, C, stream())
+        else:
+            fh, fy = h.reshape(-1), y.reshape(-1)
+            for b in range(2):
+                L.tcl_gather_add_rows_f16(fh[b * bsh:], bsh, fy[b * T * C:], T * C, unm[b], 1, n, C, stream())
+
     def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None):
-        """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps.
-        affine = (a_split, a_gap, b0): a_pos[i] = i if i < a_split else i + a_gap, b_pos[j] = b0 + j (true of every VidToMe match; lets the
-        C = 320 matches take the strip-resident kernel, csrc/merge.hip::k_tome_match320 -- same maps, bit for bit)."""
+        """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps ([2, .]
+        each without align_batch).
+        affine = (a_split, a_gap, b0): a_pos[i] = i if i < a_split else i + a_gap, b_pos[j] = b0 + j (true of the single-round VidToMe matches;
+        lets the C = 320 matches take the strip-resident kernel, csrc/merge.hip::k_tome_match320 -- same maps, bit for bit)."""
         L = self.L
         r = min(na, int(na * ratio))                                            # merge.py:90
         metric = torch.empty(2 * T, C, dtype=H16, device=self.dev)
@@ -99,12 +152,16 @@ class VidToMe:
         need = L.tcl_tome_match_workspace_bytes(na)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)        # zeroed once; every match leaves it zero again
-        mrg = torch.empty(na - r + nb, dtype=I32, device=self.dev)
-        unm = torch.empty(T, dtype=I32, device=self.dev)
-        if affine is not None:
-            L.tcl_tome_match_affine_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mrg, unm, self._ws, stream())
-        else:
-            L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, self._ws, stream())
+        aligned = self.args["align_batch"]
+        shape = (na - r + nb,) if aligned else (2, na - r + nb)
+        mrg = torch.empty(shape, dtype=I32, device=self.dev)
+        unm = torch.empty((T,) if aligned else (2, T), dtype=I32, device=self.dev)
+        for b in range(1 if aligned else 2):                                    # aligned: ONE matching over both entries (scores concatenated along dst)
+            mt, mo, uo, Bt = (metric, mrg, unm, 2) if aligned else (metric[b * T:], mrg[b], unm[b], 1)
+            if affine is not None:
+                L.tcl_tome_match_affine_f16(mt, T * C, Bt, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mo, uo, self._ws, stream())
+            else:
+                L.tcl_tome_match_f16(mt, T * C, Bt, C, a_pos, na, b_pos, nb, r, mo, uo, self._ws, stream())
         return mrg, unm, na - r + nb
 
     # ---- patch.py:14-91
@@ -117,26 +174,34 @@ class VidToMe:
     def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None):
         """x: norm1 output of one chunk: the unconditional [F*N, C] rows at x, the conditional ones xbs elements further (default
         F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]).  Returns None when this block is not merged, else
-        (merged [2,T,C], unm int32 [F*N] or None for identity, T)."""
+        (merged [2,T,C], unm int32 [F*N] ([2, F*N] without align_batch) or None for identity, T)."""
         a = self.args
         if not self.merges(N):
             return None
         L = self.L
         if xbs is None:
             xbs = F * N * C
-        if F > a["target_stride"]:
-            # patch.py:44-56 merges longer chunks in several randframe rounds (8 -> 2 -> 1) carrying the unmerged tokens along; TC-Light
-            # never configures chunk_size > target_stride (4), so only the single round is built -- refuse instead of mis-indexing.
-            raise NotImplementedError(f"VidToMe local merging of {F}-frame chunks: only chunks of <= target_stride "
-                                      f"({a['target_stride']}) frames (one randframe round) are implemented")
+        # ---- local merging (patch.py:36-58): randframe rounds until one frame is left -- one round for F <= target_stride (every TC-Light
+        # config), 8 -> 2 -> 1 / 16 -> 4 -> 1 for longer chunks, the unmerged tokens of a round riding along as extra dst tokens of the next
+        mrg1 = unm1 = None
+        seq, sbs, T, unm_pre = x, xbs, F * N, 0
+        for cur, randf in zip(*self.round_frames(F, self.randfs)):
+            a_pos, b_pos = self._positions(cur, N, randf, unm_pre)
+            single = unm_pre == 0 and cur <= a["target_stride"]                # dst = the N tokens of frame randf, src = the rest: affine
+            mrg, unm, Tn = self._match(seq, T, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=sbs,
+                                       affine=(randf * N, N, randf * N) if single else None)
+            nxt = torch.empty(2, Tn, C, dtype=H16, device=self.dev)
+            self._gather(seq, sbs, mrg, nxt, Tn * C, Tn, C)
+            if mrg1 is None:
+                mrg1, unm1 = mrg, unm
+            else:
+                mrg1 = self._compose(mrg1, mrg, 0, Tn)                          # merged slot -> row of the joined input
+                unm1 = self._compose(unm, unm1, 0, F * N)                       # joined position -> slot of the current sequence
+            unm_pre += Tn - b_pos.numel()                                       # ret_dict["unm_num"] = na - r
+            seq, sbs, T = nxt, Tn * C, Tn
         if F > 1:
-            a_pos, b_pos = self._positions(F, N, self.randf)
-            mrg1, unm1, TL = self._match(x, F * N, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=xbs,
-                                         affine=(self.randf * N, N, self.randf * N))      # dst = the N tokens of frame randf, src = the rest
-            local = torch.empty(2, TL, C, dtype=H16, device=self.dev)
-            L.tcl_gather_rows_f16(x, xbs, 0, 0, mrg1, local, TL * C, 2, TL, C, stream())
+            local, TL = seq, T
         else:
-            mrg1 = unm1 = None
             TL = N                                       # F == 1: nothing to merge locally; keep the [2, T, C] layout
             if xbs == N * C:
                 local = x.reshape(-1)[:2 * N * C].view(2, N, C)
@@ -163,13 +228,11 @@ class VidToMe:
         mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
                                      a["global_merge_ratio"], affine=(src_len, 0, src_len))
         merged = torch.empty(2, Tm, C, dtype=H16, device=self.dev)
-        L.tcl_gather_rows_f16(cat, T * C, 0, 0, mrg2, merged, Tm * C, 2, Tm, C, stream())
-        unm = torch.empty(F * N, dtype=I32, device=self.dev)
-        L.tcl_index_compose(unm2, unm1 if unm1 is not None else 0, loff, F * N, unm, stream())    # 2s-unmerge then randframe-unmerge
-        bmap = torch.empty(TL, dtype=I32, device=self.dev)                     # bank <- u(merged_tokens) (patch.py:80)
-        L.tcl_index_compose(mrg2, unm2[loff:], 0, TL, bmap, stream())
+        self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C)
+        unm = self._compose(unm2, unm1, loff, F * N)                            # 2s-unmerge then the randframe unmerges (func_warper(u_ls[::-1]))
+        bmap = self._compose(mrg2, unm2[..., loff:].contiguous() if unm2.dim() == 2 else unm2[loff:], 0, TL)     # bank <- u(merged_tokens) (patch.py:80)
         nb_ = torch.empty(2, TL, C, dtype=H16, device=self.dev)
-        L.tcl_gather_rows_f16(cat, T * C, 0, 0, bmap, nb_, TL * C, 2, TL, C, stream())
+        self._gather(cat, T * C, bmap, nb_, TL * C, TL, C)
         self.banks[name] = nb_
         if self.trace is not None:
             self.trace.append(dict(name=name, F=F, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL, bmap=bmap))

@@ -1,7 +1,8 @@
 """Golden vectors for path 1 host logic, produced by RUNNING the reference's own code (build container only).
 
-* vidtome.npz  -- utils/VidToMe/vidtome/patch.py::compute_merge on CPU f32 over a 4-chunk chain (seed bank, local-src,
-  bank-src, single frame), with the generator draws recorded.
+* vidtome.npz  -- utils/VidToMe/vidtome/patch.py::compute_merge on CPU f32 over a 5-chunk chain (seed bank, local-src,
+  bank-src, single frame), with the generator draws recorded; plus a chain of 8- / 6- / 16-frame chunks (several randframe rounds:
+  8 -> 2 -> 1) and a chain with align_batch=False (per-sample matching).
 * pipeline.npz -- Generator.temporal_denoise / ddim_sample / pred_noise (generate.py) and VidToMeGenerator.get_chunks
   (generate_utils.py) executed IN PLACE: the method source is pulled out of the reference files with `ast` at run time
   and exec'd against a stub `self` (generate.py cannot be imported here: diffusers / torch_scatter / cv2 are absent).
@@ -63,6 +64,37 @@ def golden_vidtome(R):
         out[f"c{ci}_bank_T"] = mod.global_tokens.shape[1]
         if not has_bank:
             assert torch.equal(m(x), merged)   # (with a bank m() itself raises in the reference; only merged_tokens is used)
+    # ---- branches TC-Light's own configs leave idle: (m) chunks longer than target_stride are merged in several
+    # randframe rounds, 8 -> 2 -> 1 frames, the unmerged tokens of earlier rounds joining the dst set (patch.py:43-56); (p) per-sample
+    # matching, align_batch=False (merge.py:109-118, :422+).  Separate generators / RNG streams: the c* arrays above stay what they were.
+    def chain(tag, frames, align_batch, seed):
+        a2 = dict(args, generator=None, align_batch=align_batch)
+        info2 = {"size": (12, 16), "args": a2}
+        m2 = types.SimpleNamespace()
+        m2.generator = torch.Generator(device="cpu").manual_seed(seed)
+        r2 = np.random.default_rng(1000 + seed)
+        for ci, F in enumerate(frames):
+            x = torch.from_numpy(r2.standard_normal((2 * F, N, C)).astype(np.float32))
+            g2 = torch.Generator(device="cpu")
+            g2.set_state(m2.generator.get_state())
+            randfs, cur = [], F
+            while cur > 1:                               # the draws compute_merge is about to make, in its order
+                ts = min(4, cur)
+                rf = int(torch.randint(0, ts, torch.Size([1]), generator=g2))
+                randfs.append(rf)
+                cur = sum(1 for f in range(cur) if f % ts == rf)
+            has_bank = getattr(m2, "global_tokens", None) is not None
+            coin = float(torch.rand(1, generator=g2)) if has_bank else -1.0
+            m, u, merged = patch.compute_merge(m2, x, info2)
+            T = merged.shape[1]
+            ids = torch.arange(T, dtype=torch.float32)[None, :, None].repeat(2, 1, 1)
+            out[f"{tag}{ci}_F"], out[f"{tag}{ci}_randf"], out[f"{tag}{ci}_coin"], out[f"{tag}{ci}_T"] = F, np.array(randfs), coin, T
+            out[f"{tag}{ci}_merged"] = merged[:, ::7, ::5].numpy().copy()
+            out[f"{tag}{ci}_unm"] = u(ids).reshape(2, F * N).long().numpy()          # per sample (identical rows when aligned)
+            out[f"{tag}{ci}_bank"] = m2.global_tokens[:, ::7, ::5].numpy().copy()
+            out[f"{tag}{ci}_bank_T"] = m2.global_tokens.shape[1]
+    chain("m", [8, 8, 6, 4, 16], True, 5)
+    chain("p", [4, 4, 3, 1, 8], False, 6)
     np.savez_compressed(os.path.join(HERE, "vidtome.npz"), **out)
     print("vidtome.npz:", {k: v for k, v in out.items() if np.ndim(v) == 0})
 

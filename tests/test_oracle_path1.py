@@ -25,6 +25,40 @@ def test_vidtome_chain(golden):
         assert torch.equal(r["unmerge"](ids)[:F].reshape(-1).long(), r["unm"])
 
 
+def _chain(g, tag, frames, seed, align_batch):
+    N, C = 192, 32
+    rng = np.random.default_rng(1000 + seed)
+    bank = None
+    for ci, F in enumerate(frames):
+        x = torch.from_numpy(rng.standard_normal((2 * F, N, C)).astype(np.float32))
+        r = OV.compute_merge(x, F, bank, [int(v) for v in g[f"{tag}{ci}_randf"]], float(g[f"{tag}{ci}_coin"]), align_batch=align_batch)
+        assert r["merged"].shape[1] == int(g[f"{tag}{ci}_T"])
+        assert np.array_equal(r["merged"][:, ::7, ::5].numpy(), g[f"{tag}{ci}_merged"])     # pure gathers: bit-exact
+        unm = r["unm"] if r["unm"].dim() == 2 else r["unm"][None].expand(2, -1)
+        assert np.array_equal(unm.numpy(), g[f"{tag}{ci}_unm"])
+        bank = r["bank_new"]
+        assert bank.shape[1] == int(g[f"{tag}{ci}_bank_T"])
+        assert np.array_equal(bank[:, ::7, ::5].numpy(), g[f"{tag}{ci}_bank"])
+        yield F, r
+
+
+def test_vidtome_multi_round_local_merge(golden):
+    """patch.py:43-56: chunks longer than target_stride merge in several randframe rounds (8 -> 2 -> 1, 16 -> 4 -> 1), the unmerged tokens of
+    the earlier rounds joining the dst set -- the reference's own compute_merge run on 8 / 8 / 6 / 4 / 16-frame chunks."""
+    rounds = [r["rounds"] for _, r in _chain(golden("vidtome"), "m", [8, 8, 6, 4, 16], 5, True)]
+    assert rounds == [2, 2, 1, 1, 2]
+
+
+def test_vidtome_per_sample_matching(golden):
+    """merge.py:109-118 / align_batch=False: every batch entry gets its own matching."""
+    differ = 0
+    for F, r in _chain(golden("vidtome"), "p", [4, 4, 3, 1, 8], 6, False):
+        if F > 1:
+            assert r["unm"].dim() == 2
+            differ += int(not torch.equal(r["unm"][0], r["unm"][1]))
+    assert differ >= 3
+
+
 def test_chunks_windows_fusion(golden):
     g = golden("pipeline")
     for tag, flen in {"n8": 8, "n30": 30, "n300": 300, "w120": 120, "n3": 3}.items():

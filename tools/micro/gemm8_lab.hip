@@ -1,8 +1,11 @@
 // Stand-alone lab for the 8-wave GEMM / implicit-conv kernels (no Python, no torch: builds here with hipcc, runs on the GPU box in seconds).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-comment tools/micro/gemm8_lab.hip -o gpurun_out/gemm8_lab && gpurun_out/gemm8_lab
-// For every shape: each valid tile configuration x schedule (0 = round-2 ping-pong, 1 = DMA in the MFMA shadow, 2 = two early pieces) is
+// For every shape: each valid tile configuration x schedule (0 = round-2 ping-pong, 1 = DMA in the MFMA segment, 2 = half-step pipeline) is
 // (a) compared bit for bit with schedule 0 of the same tile, (b) checked on 8192 sampled outputs against an f32 reference kernel,
 // (c) timed in interleaved rounds (median and best of 5 x 4 launches).  Output: one line per (shape, cfg, schedule) with TFLOP/s.
+#ifdef LAB_PROF
+#define G8_PROF
+#endif
 #include "../../tc_light_amd/csrc/gemm8.hip"
 #include <algorithm>
 #include <stdio.h>
@@ -66,8 +69,20 @@ int main(int argc, char** argv) {
         {1, 0, 1280, 0, 16, 23, 40, 1280, 0, "conv 1280->1280 @23x40 x16"},
         {1, 0, 1280, 0, 16, 23, 40, 2560, 0, "conv 2560->1280 @23x40 x16"},
         {1, 0, 1280, 0, 64, 12, 20, 1280, 0, "conv 1280->1280 @12x20 x64"},
+        // the metric's pass (300 x 1280 x 720, block-major): up to 1.5 M level-0 rows per launch
+        {0, 1474560, 320, 320, 0, 0, 0, 0, 0, "lin 1474560x320x320"},
+        {0, 1474560, 320, 1280, 0, 0, 0, 0, 0, "lin 1474560x320x1280 (ff2, level 0)"},
+        {0, 368640, 640, 2560, 0, 0, 0, 0, 0, "lin 368640x640x2560 (ff2, level 1)"},
+        {0, 92160, 1280, 5120, 0, 0, 0, 0, 0, "lin 92160x1280x5120 (ff2, level 2)"},
+        {1, 0, 320, 0, 64, 90, 160, 320, 0, "conv 320->320 @90x160 x64"},
+        {1, 0, 320, 0, 64, 90, 160, 640, 0, "conv 640->320 @90x160 x64"},
+        {1, 0, 640, 0, 64, 45, 80, 640, 0, "conv 640->640 @45x80 x64"},
+        {1, 0, 640, 0, 64, 45, 80, 1280, 0, "conv 1280->640 @45x80 x64"},
+        {1, 0, 1280, 0, 64, 23, 40, 1280, 0, "conv 1280->1280 @23x40 x64"},
+        {1, 0, 1280, 0, 64, 23, 40, 2560, 0, "conv 2560->1280 @23x40 x64"},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
+    const unsigned smask = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0x7u;      // bit s = time schedule s
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float* derr; CK(hipMalloc(&derr, 8192 * 4));
@@ -98,6 +113,7 @@ int main(int argc, char** argv) {
             double med[3], best[3];
             std::vector<float> t[3];
             for (int sched = 0; sched < 3; ++sched) {
+                if (sched && !((smask >> sched) & 1)) continue;
                 g_gemm8_sched = sched;
                 _Float16* C = sched == 0 ? C0 : C1;
                 CK(hipMemsetAsync(C, 0xff, (size_t)M * N * 2, st));
@@ -117,6 +133,7 @@ int main(int argc, char** argv) {
             }
             for (int round = 0; round < 5; ++round)
                 for (int sched = 0; sched < 3; ++sched) {
+                    if (!((smask >> sched) & 1)) { t[sched].push_back(1e9f); continue; }
                     g_gemm8_sched = sched;
                     CK(hipEventRecord(e0, st));
                     for (int r = 0; r < 4; ++r) gemm8_dispatch(cfg, A, Wt, nullptr, nullptr, C1, M, N, K, lda, K, N, N, 0, cp, st);
@@ -125,8 +142,24 @@ int main(int argc, char** argv) {
                     t[sched].push_back(ms / 4);
                 }
             for (int sched = 0; sched < 3; ++sched) { std::sort(t[sched].begin(), t[sched].end()); med[sched] = t[sched][2]; best[sched] = t[sched][0]; }
+#ifdef LAB_PROF
+            for (int sched = 1; sched < 3; ++sched) {        // segment cycles of the K loop (wave 0 = group 0, wave 4 = group 1), mean over 64 blocks
+                g_gemm8_sched = sched;
+                unsigned long long* pb; CK(hipMalloc(&pb, 64 * 2 * 5 * 8)); CK(hipMemset(pb, 0, 64 * 2 * 5 * 8));
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g8_prof_buf), &pb, sizeof(pb)));
+                gemm8_dispatch(cfg, A, Wt, nullptr, nullptr, C1, M, N, K, lda, K, N, N, 0, cp, st); CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hp(640); CK(hipMemcpy(hp.data(), pb, 640 * 8, hipMemcpyDeviceToHost));
+                const int nk = K / 32;
+                for (int g = 0; g < 2; ++g) {
+                    double sm[5] = {0, 0, 0, 0, 0};
+                    for (int b = 0; b < 64; ++b) for (int i = 0; i < 5; ++i) sm[i] += (double)hp[(b * 2 + g) * 5 + i] / 64 / nk;
+                    printf("      prof cfg %d sched %d group %d: cycles per K step: barrier1 %.0f | L %.0f | barrier2 %.0f | M %.0f | vmcnt wait %.0f | sum %.0f\n", cfg, sched, g, sm[0], sm[1], sm[2], sm[3], sm[4], sm[0] + sm[1] + sm[2] + sm[3] + sm[4]);
+                }
+                pb = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g8_prof_buf), &pb, sizeof(pb)));
+            }
+#endif
             printf("   cfg %d (%s):", cfg, cfg == 1 ? "256x320" : cfg == 2 ? "128x320" : cfg == 3 ? "256x256" : "128x256");
-            for (int sched = 0; sched < 3; ++sched) printf("  s%d %8.1f us %6.0f TF (best %6.0f)", sched, med[sched] * 1e3, flop / med[sched] / 1e9, flop / best[sched] / 1e9);
+            for (int sched = 0; sched < 3; ++sched) if ((smask >> sched) & 1) printf("  s%d %8.1f us %6.0f TF (best %6.0f)", sched, med[sched] * 1e3, flop / med[sched] / 1e9, flop / best[sched] / 1e9);
             printf("\n");
         }
         CK(hipFree(A)); CK(hipFree(Wt)); CK(hipFree(C0)); CK(hipFree(C1));

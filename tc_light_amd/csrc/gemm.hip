@@ -17,6 +17,7 @@
 // stays in that XCD's L2 while W (small) is L2-resident everywhere.
 #include "common.h"
 #include <stdio.h>
+#include <string.h>
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
 #include <unordered_map>
@@ -520,6 +521,23 @@ static bool cfg_ok(int cfg, int M, int N, int K, int ldc, int ldr, bool has_resi
     return true;
 }
 
+// Which tiles the tuner may time for a shape -- and which a persistent table entry may name (a stale or hand-edited table must
+// not route a shape to a tile that does not divide N or that drops the K split its candidates were measured with).
+static bool tile_ok(int cfg, int M, int N, int K, int splits) {
+    const int t128 = cdiv(M, 128) * cdiv(N, 128);
+    switch (cfg) {
+        case 1: return true;
+        case 2: case 3: return t128 < 4096;
+        case 4: return t128 < 1024;
+        case 11: return t128 >= 256;
+        case 5: return splits == 1 && K >= 512 && N % 320 == 0 && cdiv(M, 256) * (N / 320) >= 96;
+        case 6: return splits == 1 && K >= 512 && N % 320 == 0 && cdiv(M, 128) * (N / 320) >= 96;
+        case 7: return splits == 1 && K >= 512 && N % 256 == 0 && cdiv(M, 256) * (N / 256) >= 96;
+        case 8: return splits == 1 && K >= 512 && N % 256 == 0 && cdiv(M, 128) * (N / 256) >= 96;
+    }
+    return false;
+}
+
 // ---- automatic choice: a per-process cache keyed by the problem shape, filled on first use by timing the valid candidates on the
 // caller's stream (hipEvents; the tuning call synchronises the stream, later calls are a hash lookup).  Numerics do not depend
 // on the outcome: every tile configuration accumulates each output element over k in the same order (16-wide MFMA blocks in
@@ -541,6 +559,7 @@ struct TuneKeyHash {
     }
 };
 static std::unordered_map<TuneKey, int, TuneKeyHash> g_tune_cache;
+#define TUNE_MAGIC "!tcl-gemm-table gfx950 v3"        // bump when tiles / schedules change: older tables are refused, not trusted
 static int g_autotune = 1;
 
 static int split_rule(int M, int N, int K, int act) {
@@ -579,22 +598,16 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     auto it = g_tune_cache.find(key);
     if (it != g_tune_cache.end()) {
         // the key leaves the leading dimensions out: a cached (or file-loaded) tile is re-validated for this call's ldc / ldr
-        const int c = cfg_ok(it->second, M, N, K, ldc, ldr, hasr, act, cp) ? it->second : fallback;
+        const int c = (cfg_ok(it->second, M, N, K, ldc, ldr, hasr, act, cp) && tile_ok(it->second, M, N, K, splits)) ? it->second : fallback;
         return run_cfg(c, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     }
     if (g_autotune == 2)      // table-only mode: shapes the loaded table does not know take the static heuristic (no timing, no host sync)
         return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-    // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs
+    // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs (tile_ok)
     int cand[9], nc = 0;
-    const int t128 = cdiv(M, 128) * cdiv(N, 128);
-    cand[nc++] = 1;
-    if (t128 < 4096) { cand[nc++] = 2; cand[nc++] = 3; }
-    if (t128 < 1024) cand[nc++] = 4;
-    if (t128 >= 256) cand[nc++] = 11;
-    if (splits == 1 && K >= 512) {
-        if (N % 320 == 0 && N % 256 != 0) { if (cdiv(M, 256) * (N / 320) >= 96) cand[nc++] = 5; if (cdiv(M, 128) * (N / 320) >= 96) cand[nc++] = 6; }
-        if (N % 256 == 0) { if (cdiv(M, 256) * (N / 256) >= 96) cand[nc++] = 7; if (cdiv(M, 128) * (N / 256) >= 96) cand[nc++] = 8; }
-    }
+    static const int all_cfgs[9] = {1, 2, 3, 4, 11, 5, 6, 7, 8};
+    for (int c : all_cfgs)
+        if (tile_ok(c, M, N, K, splits)) cand[nc++] = c;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     // two interleaved rounds, minimum per candidate: one disturbed measurement (clock ramp, a profiler attached) must not pick the tile
@@ -634,6 +647,7 @@ int tcl_gemm_tune_save(const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return TCL_EINVAL;
     fprintf(f, "# tc_light_amd GEMM tile table, gfx950: conv M N K act hasr Hin Win Cin stride Hup -> cfg (csrc/gemm.hip)\n");
+    fprintf(f, "%s\n", TUNE_MAGIC);
     for (const auto& kv : g_tune_cache) {
         const TuneKey& k = kv.first;
         fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d\n", k.conv, k.M, k.N, k.K, k.act, k.hasr, k.Hin, k.Win, k.Cin, k.stride, k.Hup, kv.second);
@@ -646,9 +660,12 @@ int tcl_gemm_tune_load(const char* path) {
     FILE* f = fopen(path, "r");
     if (!f) return TCL_EINVAL;
     char line[256];
+    bool versioned = false;
     while (fgets(line, sizeof line, f)) {
         TuneKey k; int cfg;
+        if (!strncmp(line, TUNE_MAGIC, strlen(TUNE_MAGIC))) { versioned = true; continue; }
         if (line[0] == '#') continue;
+        if (!versioned) { fclose(f); return TCL_EINVAL; }          // a table of another kernel generation / architecture: measured with other tiles
         if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d %d", &k.conv, &k.M, &k.N, &k.K, &k.act, &k.hasr, &k.Hin, &k.Win, &k.Cin, &k.stride, &k.Hup, &cfg) != 12) continue;
         if (!((cfg >= 1 && cfg <= 8) || cfg == 11)) continue;          // only ids the cached path may run
         g_tune_cache[k] = cfg;

@@ -44,15 +44,10 @@ class Generator:
         self.dist = dist or Dist()
         self.scheduler = scheduler or DPMSolverSDEScheduler()
         c = self.cfg
-        if int(c.chunk_size) > int(self.unet.tome.args["target_stride"]):
-            raise NotImplementedError(f"generation.chunk_size {c.chunk_size} > VidToMe target_stride {self.unet.tome.args['target_stride']}: the "
-                                      "multi-round local merge of patch.py:44-56 is not implemented (every TC-Light config uses 4)")
-        if not c.align_batch:
-            raise NotImplementedError("generation.align_batch: false is not implemented (TC-Light runs VidToMe with align_batch=True)")
         # vidtome.apply_patch(...) (generate_utils.py:98-100); max_downsample is NOT forwarded by the reference (default 2)
         t = self.unet.tome
         t.args.update(local_merge_ratio=c.local_merge_ratio, merge_global=c.merge_global, global_merge_ratio=c.global_merge_ratio,
-                      global_rand=c.global_rand)
+                      global_rand=c.global_rand, align_batch=bool(c.align_batch))
         self.batch_size = 2
         self.timing = {}
 

@@ -49,8 +49,9 @@ def load_gemm_table(L):
         L.tcl_gemm_autotune(0)
         return
     path = os.environ.get("TCL_GEMM_TABLE", GEMM_TABLE)
-    if os.path.exists(path):
-        L.tcl_gemm_tune_load(path)
+    if os.path.exists(path) and L.tcl_gemm_tune_load(path) != 0:
+        import warnings
+        warnings.warn(f"GEMM tile table {path} was written for other kernels (no / other version line): ignored, shapes are timed on first use")
     L.tcl_gemm_autotune(2 if mode == "table" else 1)
 
 
@@ -285,7 +286,7 @@ class UNetEngine:
                 qkv = o.gemm(merged, blk["qkv"], M=2 * T)
                 a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
                 y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
-                L.tcl_gather_add_rows_f16(h[off * N:], xbs, y, T * C, unm if unm is not None else 0, 2, F * N, C, stream())
+                self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C)      # u_a(...) + x (patch.py:178-179)
                 self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
                 off += F
             # (running the attention of alternate chunks on a second stream as well was measured: no further gain)

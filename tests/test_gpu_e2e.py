@@ -86,7 +86,7 @@ def test_config1_end_to_end():
     # the same two optimiser stages on the oracle, started from the ENGINE's decoded frames: separates the engine's stage-1/2 arithmetic from
     # the conditioning of the reference's algorithm (Adam's first steps are +-lr whatever the gradient's size: 0.05*16/8 * C0 = 0.028 RGB per
     # step here, so a 1e-3 input difference is amplified -- the oracle fed with 1e-3-perturbed inputs moves by 1.2-1.4e-2 rel-L2 itself)
-    _, final_h, _, _ = E.oracle_post_opt(stages["clean"].cpu(), d["past_flows"], d["masks"], inv, c, n)
+    _, final_h, l1s, l2s = E.oracle_post_opt(stages["clean"].cpu(), d["past_flows"], d["masks"], inv, c, n)
     # ... and the oracle against ITSELF with its input perturbed at the f32 rounding level (1e-7 relative): the reference's optimiser is
     # chaotic at the pixel level -- Adam's update is +-lr whatever the gradient's size, so rounding noise decides the sign wherever the
     # gradient nearly cancels and 105 iterations spread that -- which bounds what ANY two implementations can agree to after stage 2
@@ -109,7 +109,32 @@ def test_config1_end_to_end():
               # iteration -- measured 1e-5 at the last one)
               r["final_same_decoded"] < 1.5 * max(r["oracle_vs_oracle_1e7"], 2e-3),
               r["final"] < 1.5 * max(r["oracle_vs_oracle_1e7"], 2e-3)]
-    loss_ok = np.allclose(l1h, np.asarray(l1), rtol=2e-2) and np.allclose(l2h, np.asarray(l2), rtol=2e-2)
+    # per-iteration LOSSES (105 of them): against the oracle started from the engine's own decoded frames they must agree to rounding (measured
+    # 1e-5 relative; asserted 2e-4) -- the chaos above lives in single pixels, global means do not see it; against the oracle's whole path
+    # (decoded frames 1e-3 apart) to 2e-3
+    loss_ok = (np.allclose(l1h, np.asarray(l1s), rtol=2e-4) and np.allclose(l2h, np.asarray(l2s), rtol=2e-4)
+               and np.allclose(l1h, np.asarray(l1), rtol=2e-3) and np.allclose(l2h, np.asarray(l2), rtol=2e-3))
+    print(f"[e2e config 1] loss trajectories, max relative difference: same decoded frames stage 1 {np.abs(l1h / np.asarray(l1s) - 1).max():.2e} "
+          f"stage 2 {np.abs(l2h / np.asarray(l2s) - 1).max():.2e}; whole path {np.abs(l1h / np.asarray(l1) - 1).max():.2e} / {np.abs(l2h / np.asarray(l2) - 1).max():.2e}")
+    # statistics of the FINAL frames that are not chaotic (sign noise of single codebook rows averages out): per-frame mean colour,
+    # mean colour of 64 groups of tracks (track id mod 64), and the masked warp error of the result (the flow term of the loss, evaluated
+    # on the outputs).  Scale: the oracle's own distance between its two runs 1e-7 apart.
+    fl, mk = d["past_flows"], d["masks"]
+
+    def stats(img):
+        fm = img.mean(dim=(2, 3))                                                   # [n, 3]
+        flat = img.permute(0, 2, 3, 1).reshape(-1, 3)
+        grp = (inv.long() % 64)
+        gm = torch.zeros(64, 3).index_add_(0, grp, flat) / torch.bincount(grp, minlength=64).clamp_min(1)[:, None]
+        warped = E.O2.warp_flow(img[:-1], fl[1:])
+        we = ((warped - img[1:]).abs() * mk[1:]).mean()
+        return fm, gm, we
+    sh, so, sp, si = stats(out.cpu()), stats(final_h), stats(final_p), stats(final_i)
+    d_fm, d_gm, d_we = (sh[0] - so[0]).abs().max().item(), (sh[1] - so[1]).abs().max().item(), abs(sh[2] / so[2] - 1).item()
+    s_fm, s_gm, s_we = (sp[0] - si[0]).abs().max().item(), (sp[1] - si[1]).abs().max().item(), abs(sp[2] / si[2] - 1).item()
+    print(f"[e2e config 1] non-chaotic statistics, engine vs oracle from the same decoded frames (oracle vs itself 1e-7 apart): per-frame mean colour "
+          f"{d_fm:.2e} ({s_fm:.2e}), track-group mean colour {d_gm:.2e} ({s_gm:.2e}), masked warp error rel {d_we:.2e} ({s_we:.2e})")
+    checks += [d_fm < max(3 * s_fm, 3e-4), d_gm < max(3 * s_gm, 3e-4), d_we < max(3 * s_we, 3e-3)]
 
     # ------------------------------------------------------------------ the oracle deciding its own matches
     # (the first 2 of the 4 steps by default -- 60 merges -- to keep the test inside ~5 minutes of oracle time; TCL_E2E_COMPUTED=4 runs all)

@@ -157,6 +157,37 @@ def test_attention_heavy_tail_and_sink_precision(L, qscale, sink):
     assert rel(o[:, rows], ref) < 7e-4
 
 
+def test_attention_trained_like_logits(L):
+    """Speculative softmax on logits shaped like a trained UNet's self-attention rather than white noise: every head has its
+    own temperature (logit std from 0.5 to 9 bits across the 8 heads), token 0 is an attention SINK that every query scores 12-25 bits above
+    the bulk, and keys carry a smooth positional component so neighbouring tokens score alike (long runs of tiles where the running maximum
+    does not move, then jumps).  Sampled rows against the f32 reference; the result must also equal the exact-maximum kernel's to f16 rounding."""
+    d, B, Tq, Hh = 40, 2, 20000, 8
+    C = Hh * d
+    g = torch.Generator(device="cuda").manual_seed(11)
+    temp = torch.tensor([0.35, 0.6, 1.0, 1.6, 2.5, 4.0, 6.0, 9.0], device="cuda").repeat_interleave(d)        # per-head query scale
+    pos = torch.linspace(0, 6.28318 * 3, Tq, device="cuda")[:, None]
+    wave = torch.cat([torch.sin(pos * (1 + j)) for j in range(4)], 1) @ torch.randn(4, C, device="cuda", generator=g) * 0.7
+    q = ((torch.randn(B, Tq, C, device="cuda", generator=g) + wave) * temp).to(H)
+    k = (torch.randn(B, Tq, C, device="cuda", generator=g) + wave).to(H)
+    v = torch.randn(B, Tq, C, device="cuda", generator=g).to(H)
+    u = torch.randn(C, device="cuda", generator=g)
+    u = (u.view(Hh, d) / u.view(Hh, d).norm(dim=1, keepdim=True)).reshape(C)
+    k[:, 0] = (u * 9.0).to(H)                                                    # the sink key ...
+    q = (q.float() + u * temp.clamp(max=2.0) * 4.0).to(H)                       # ... that every query leans towards
+    o = torch.empty_like(q)
+    wq, wkv = ws_bytes(L.tcl_attention_q_bytes(B, Hh, Tq, d)), ws_bytes(L.tcl_attention_kv_bytes(B, Hh, Tq, d))
+    L.tcl_attention_f16(q, C, Tq * C, k, C, Tq * C, v, C, Tq * C, o, C, Tq * C, B, Hh, Tq, Tq, d, d ** -0.5, 1, 1, wq, wkv, st())
+    rows = torch.arange(0, Tq, 41, device="cuda")
+    qq = q[:, rows].float().view(B, -1, Hh, d).transpose(1, 2)
+    kk, vv = (t.float().view(B, Tq, Hh, d).transpose(1, 2) for t in (k, v))
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, -1, C)
+    assert torch.isfinite(o).all()
+    per_head = ((o[:, rows].float() - ref).view(B, -1, Hh, d).norm(dim=(0, 1, 3)) / ref.view(B, -1, Hh, d).norm(dim=(0, 1, 3))).cpu()
+    print("[attention, trained-like logits] rel-L2 per head:", [f"{x:.1e}" for x in per_head.tolist()])
+    assert rel(o[:, rows], ref) < 7e-4 and per_head.max() < 1.5e-3
+
+
 @pytest.mark.parametrize("na,nb,C,ratio", [(32400, 10800, 320, 0.6),     # local (random-frame) merge of a 4-frame chunk at level 0
                                            (23760, 23760, 320, 0.5),     # global merge against an equally long bank
                                            (8100, 2700, 640, 0.6),       # level 1

@@ -231,6 +231,58 @@ def test_vidtome_maps_vs_oracle(L):
         bank = tome.banks["blk"].cpu().float()       # continue the chain from the HIP bank so later rounds stay comparable
 
 
+def _restored(merged, unm, F, N):
+    """unmerge applied to the merged tokens themselves: [2, F*N, C] (slot numbering of the unmerged tokens is free, see above)."""
+    if unm is None:
+        return merged
+    if unm.dim() == 1:
+        return merged[:, unm]
+    return torch.stack([merged[b, unm[b]] for b in range(2)])
+
+
+def test_vidtome_multi_round_and_per_sample_vs_oracle(L):
+    """The two compute_merge branches TC-Light's own configs leave idle: chunks of more than target_stride frames
+    (several randframe rounds, 8 -> 2 -> 1 and 16 -> 4 -> 1, patch.py:43-56) and per-sample matching (align_batch=False, merge.py:109-118).
+    Same f16 tokens -> HIP path vs the oracle's f16-emulating rule (the oracle itself is pinned bit-exactly to the reference's
+    compute_merge on these branches: tests/test_oracle_path1.py)."""
+    from oracle import vidtome as OV
+    from tc_light_amd.vidtome import VidToMe
+    g = np.random.default_rng(17)
+    N = 150
+    for C, aligned, chain in ((320, True, [(8, [3, 0], 0.9), (8, [1, 1], 0.2), (6, [2], 0.7), (16, [0, 3], 0.4), (4, [1], 0.8)]),
+                              (640, False, [(4, [2], 0.9), (4, [0], 0.1), (8, [3, 0], 0.6), (1, [], 0.3), (3, [1], 0.7)])):
+        tome = VidToMe("cuda", align_batch=aligned)
+        bank = None
+        for F, randfs, coin in chain:
+            base = g.standard_normal((1, N, C)).astype(np.float32)
+            x = torch.from_numpy(base + 0.3 * g.standard_normal((2 * F, N, C)).astype(np.float32)).half()
+            tome.draws = [(randfs, coin)]
+            tome.begin_forward(F, (10, 15))
+            merged, unm, T = tome.compute_merge("blk", x.cuda(), F, N, C)
+            r = OV.compute_merge(x.float(), F, bank, randfs, coin, emulate_f16=True, align_batch=aligned)
+            assert T == r["merged"].shape[1], (F, T, r["merged"].shape)
+            assert r["rounds"] == len(randfs)
+            if unm is not None and not aligned:
+                assert unm.dim() == 2
+            mh = merged.cpu().float()
+            rest_h = _restored(mh, unm.cpu().long() if unm is not None else None, F, N)
+            rest_o = _restored(r["merged"], r["unm"], F, N)
+            agree = (rest_h == rest_o).all(-1).float().mean().item()
+            assert agree > 0.99, (C, aligned, F, agree)
+            if agree == 1.0:
+                hv = torch.from_numpy(g.standard_normal(C).astype(np.float32))
+                assert torch.equal((mh @ hv).sort(-1).values, (r["merged"] @ hv).sort(-1).values)                                   # same merged set
+                assert torch.equal((tome.banks["blk"].cpu().float() @ hv).sort(-1).values, (r["bank_new"] @ hv).sort(-1).values)     # same bank, as a set
+            # unmerge_add = residual + unmerge, per sample
+            h = torch.zeros(2 * F * N, C, dtype=H, device="cuda")
+            y = torch.randn(2, T, C, device="cuda").to(H)
+            tome.unmerge_add(h, F * N * C, y, T, unm, F * N, C)
+            want = _restored(y.cpu().float(), unm.cpu().long() if unm is not None else None, F, N).reshape(2 * F * N, C)
+            assert torch.equal(h.cpu().float(), want)
+            bank = tome.banks["blk"].cpu().float()
+    torch.cuda.synchronize()
+
+
 def test_splitk_gemm_conv(L):
     """small-M deep-K problems take the split-K path once a workspace is registered; result must match the direct path."""
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")

@@ -148,3 +148,27 @@ def test_producer_masks_and_ids(ops, golden):
     ids, k = flow_ids.get_flowid(d5["frames"].cuda(), fwd.cuda(), torch.from_numpy(g["softmask"]).cuda(), rgb_threshold=0.01)
     assert np.array_equal(ids.cpu().numpy().astype(np.int64), g["flowid"])
     assert k == int(g["flowid"].max()) + 1
+
+
+def test_load_data_composition_vs_oracle(ops):
+    """B1 (VideoDataParser.load_data, video_dataparser.py:43-61): masks -> track ids -> voxelisation as ONE composition, the engine's
+    `soft_masks_and_ids` against the oracle's three steps chained the same way (the masks that decide the id splats are each side's own).
+    Integer-pixel motion with a moving occluder: mask values sit away from the 0.5 cut, so the ids must be identical, K included."""
+    from oracle import path2 as O
+    from tc_light_amd import flow_ids
+    d6 = synth.video_clip(6, 64, 80, seed=33, shift=(2.0, 1.0), jitter=0.0)
+    frames = d6["frames"].clone()
+    for i in range(6):                                    # an occluder moving the other way: forward-backward inconsistency + colour change
+        frames[i, :, 20:34, 50 - 4 * i:62 - 4 * i] = 0.9
+    past = d6["past_flows"]
+    fwd = -past.roll(-1, 0)
+    fwd[-1] = 0
+    masks, inv, k = flow_ids.soft_masks_and_ids(frames.cuda(), fwd.cuda(), past.cuda(), alpha=0.5)
+    om = O.get_soft_mask_bwds(frames, fwd, past, alpha=0.5)
+    oid = O.get_flowid(frames, fwd, om)
+    oinv = O.voxelization_time_only(oid)
+    np.testing.assert_allclose(masks.cpu().numpy(), om.numpy(), atol=2e-5)
+    assert ((om - 0.5).abs() > 1e-3).all(), "the clip must not put a mask value on the 0.5 cut"
+    assert np.array_equal(inv.cpu().numpy().astype(np.int64), oinv.numpy())
+    assert k == int(oinv.max()) + 1 and k > 64 * 80 and k < 6 * 64 * 80     # tracks are re-used AND new ones appear
+

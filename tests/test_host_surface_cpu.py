@@ -212,12 +212,20 @@ def test_frame_ids_and_example_configs():
         os.chdir(cwd)
 
 
-def test_generator_refuses_unsupported_vidtome_settings():
-    """chunk_size > target_stride and align_batch=False are refused up front instead of mis-indexing the match."""
+def test_generator_forwards_vidtome_settings():
+    """Round 3: chunk_size > target_stride (multi-round local merge, patch.py:43-56) and align_batch=False (merge.py:109-118) are built, so
+    the Generator accepts them and forwards align_batch to the patch arguments like apply_patch does (generate_utils.py:98-100)."""
     from types import SimpleNamespace
     from tc_light_amd.generate import Generator
-    stub = SimpleNamespace(dev="cpu", tome=SimpleNamespace(args=dict(target_stride=4)))
-    with pytest.raises(NotImplementedError):
-        Generator(stub, None, dict(chunk_size=8))
-    with pytest.raises(NotImplementedError):
-        Generator(stub, None, dict(align_batch=False))
+    from tc_light_amd.vidtome import VidToMe
+    stub = SimpleNamespace(dev="cpu", tome=SimpleNamespace(args=dict(target_stride=4, align_batch=True)))
+    Generator(stub, None, dict(chunk_size=8))
+    Generator(stub, None, dict(align_batch=False))
+    assert stub.tome.args["align_batch"] is False
+    # the randframe rounds of a long chunk: the dst frames of one round are the frames of the next (8 -> 2 -> 1, 16 -> 4 -> 1, 6 -> 1 | 2)
+    rf = VidToMe.round_frames(SimpleNamespace(args=dict(target_stride=4), rng=None), 8, [3, 0])
+    assert rf == ([8, 2], [3, 0])
+    assert VidToMe.round_frames(SimpleNamespace(args=dict(target_stride=4), rng=None), 16, [0, 3])[0] == [16, 4]
+    assert VidToMe.round_frames(SimpleNamespace(args=dict(target_stride=4), rng=None), 6, [2])[0] == [6]
+    assert VidToMe.round_frames(SimpleNamespace(args=dict(target_stride=4), rng=None), 6, [1, 0])[0] == [6, 2]
+    assert VidToMe.round_frames(SimpleNamespace(args=dict(target_stride=4), rng=None), 1)[0] == []

@@ -38,12 +38,16 @@ int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, floa
  * (NULL to skip).  X, Y: `planes` contiguous h*w planes (= batch*channels). */
 size_t tcl_msssim_workspace_bytes(int planes, int h, int w);
 int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, float* value, float* gradX, void* ws, hipStream_t st);
-/* TVLoss(weight)(x) and its gradient  utils/loss_utils.py:324-340.  ws16: 1 KiB of scratch. */
+/* TVLoss(weight)(x) and its gradient  utils/loss_utils.py:324-340.  ws16: 2 KiB of scratch (fixed-point loss accumulators). */
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st);
 /* torch.optim.Adam single-tensor step (generate.py:381,483-487); g is consumed and zeroed. step counts from 1. */
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
+/* Are the track ids of every frame pairwise distinct (true of get_flowid's output, utils/flow_utils.py:56-93: a pixel of frame i takes the id
+ * of ONE pixel of frame i-1 or a fresh id)?  *result (device int) <- 1 / 0; scratch: K ints.  Stage 2 then accumulates codebook rows one frame
+ * at a time without atomics -- bit-reproducible -- by passing ids_unique = 1 below; with 0 it falls back to float atomics (any id layout). */
+int tcl_track_ids_unique(const int* unq_inv, int N, int H, int W, size_t K, int* scratch, int* result, hipStream_t st);
 /* RGB2SH(torch_scatter.scatter(pixels, unq_inv, reduce='mean'))  generate.py:477-479 -> feat [3,K] planar.  cnt: K floats scratch. */
-int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, hipStream_t st);
+int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, int ids_unique, hipStream_t st);
 
 /* Whole-stage drivers: every iteration is enqueued on `st`; no host synchronisation inside.
  * sched (HOST) int32 [iters][batch]: frame ids of each mini-batch, -1 pads a short batch (stands in for
@@ -60,7 +64,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
 /* Generator.unique_tensor_optimization  generate.py:453-533.  feat/g/m/v [3,K] planar, feat initialised by tcl_scatter_mean_rgb2sh;
  * images_out [N,3,h,w] (may be NULL) receives the final gather. */
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
-                          size_t K, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim,
+                          size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim,
                           float lambda_flow, float lambda_tv, float* feat, float* g, float* m, float* v, float* losses,
                           float* images_out, void* ws, hipStream_t st);
 
@@ -75,7 +79,7 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
                       int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow, const float* exposure, float* g,
                       float* loss_part, void* ws, hipStream_t st);
 int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
-                           const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                           int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
                            float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st);
 
 /* ===================================================================== path 1: denoising loop (f16, f32 accumulate)

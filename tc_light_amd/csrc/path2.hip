@@ -16,7 +16,24 @@
 #include <string.h>
 
 #define SH_C0 0.28209479177387814f
-#define ACC_SLOTS 32   // loss accumulators: [ACC_SLOTS][4] floats = {l1, tv_h, tv_w, flow}
+#define ACC_SLOTS 32   // loss accumulators: [ACC_SLOTS][4] fixed-point cells = {l1, tv_h, tv_w, flow}
+
+// ---- run-to-run determinism (round 3).  Every reduction whose order the hardware chooses -- block partial sums meeting in one cell, the
+// bicubic scatter of the warp's backward pass -- accumulates in 64-bit FIXED POINT: integer addition is associative, so the result does not
+// depend on the order the atomics land in, and two runs (or two ranks replicating the optimiser) produce the same bits.  The scale of each
+// accumulator is a power of two chosen from the quantity's range (value * 2^k is exact in f32; the conversion rounds to 2^-k once per
+// contribution, far below the f32 rounding of the float sums it replaces).  Codebook rows are accumulated without atomics at all: the
+// track ids of get_flowid are unique within a frame (tcl_track_ids_unique verifies it once per run), so one frame of the mini-batch at a time
+// is a conflict-free read-modify-write, and the frames go in a fixed order.
+typedef long long fx_t;
+#define FX_SSIM 1073741824.f            // 2^30: per-block sums of SSIM values, |.| <= TW*TH
+#define FX_ACC 1048576.f                // 2^20: loss sums over a mini-batch (<= ~1e8)
+#define FX_FLOW 4294967296.f            // 2^32: mask * bicubic weights landing on one pixel of the previous frame
+#define FX_EXPO 281474976710656.f       // 2^48: exposure gradient components (sums of image * pixel gradient)
+__device__ __forceinline__ void fx_add(fx_t* p, float v, float scale) {
+    atomicAdd((unsigned long long*)p, (unsigned long long)__float2ll_rn(v * scale));
+}
+__device__ __forceinline__ float fx_get(fx_t v, float inv_scale) { return (float)((double)v * (double)inv_scale); }
 #define TW 32
 #define TH 16
 #define HALO 10
@@ -92,30 +109,40 @@ __global__ void k_apply_exposure(const float* __restrict__ src, const int* __res
         }
     }
 }
-// grad_expo[f] += d(loss)/dM from grad of the clamped output (atomics: one set of 12 per block)
+// d(loss)/dM of cat row j from the gradient of its clamped output -> efx[j][12] (fixed point; ordered add into grad_expo by k_expo_fin).
+// Rows j >= b are the "previous frame" images: their gradient is the flow term's scatter, held in fixed point (gpre, see k_flow_loss).
 __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ expo,
-                               const float* __restrict__ gout, float* __restrict__ gexpo, int P) {
+                               const float* __restrict__ gimg, const fx_t* __restrict__ gpre, float pre_scale, int b, fx_t* __restrict__ efx, int P) {
     __shared__ float red[16];
     const int j = blockIdx.y, f = idx[j];
     const float* M = expo + (size_t)f * 12;
     float m[12], acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { m[i] = M[i]; acc[i] = 0.f; }
-    const float* s = src + (size_t)f * 3 * P; const float* g = gout + (size_t)j * 3 * P;
+    const float* s = src + (size_t)f * 3 * P;
+    const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
+    const fx_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         float x[3] = {s[p], s[P + p], s[2 * P + p]};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float t = x[0] * m[c] + x[1] * m[4 + c] + x[2] * m[8 + c] + m[c * 4 + 3];
-            float gc = (t >= 0.f && t <= 1.f) ? g[c * P + p] : 0.f;
+            float gv = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
+            float gc = (t >= 0.f && t <= 1.f) ? gv : 0.f;
             acc[c] += x[0] * gc; acc[4 + c] += x[1] * gc; acc[8 + c] += x[2] * gc; acc[c * 4 + 3] += gc;
         }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         float r = block_sum(acc[i], red);
-        if (threadIdx.x == 0 && r != 0.f) atomicAdd(gexpo + (size_t)f * 12 + i, r);
+        if (threadIdx.x == 0 && r != 0.f) fx_add(efx + (size_t)j * 12 + i, r, FX_EXPO);
     }
+}
+// grad_expo[idx[j]] += efx[j], rows in order (a frame may sit in the batch twice: as a current and as a previous frame)
+__global__ void k_expo_fin(const fx_t* __restrict__ efx, const int* __restrict__ idx, int rows, float* __restrict__ gexpo) {
+    const int i = threadIdx.x;
+    if (i >= 12) return;
+    for (int j = 0; j < rows; ++j) gexpo[(size_t)idx[j] * 12 + i] += fx_get(efx[(size_t)j * 12 + i], 1.f / FX_EXPO);
 }
 // out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
 __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
@@ -128,18 +155,36 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
         for (int c = 0; c < 3; ++c) o[c * P + p] = fminf(fmaxf(feat[c * K + id] * SH_C0 + 0.5f, 0.f), 1.f);
     }
 }
+// d(loss)/d(codebook): cat row j0 + blockIdx.y.  ATOMIC == false: the ids of one frame are distinct, so a launch over ONE row is a conflict-free
+// read-modify-write and the rows of a mini-batch are launched one after the other (fixed order: deterministic, and no atomic unit in the way);
+// ATOMIC == true (ids that repeat inside a frame): all rows in one launch, float atomics, order not reproducible.
+template <bool ATOMIC>
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                               const float* __restrict__ gout, float* __restrict__ gfeat, int P, size_t K) {
-    const int j = blockIdx.y, f = fidx[j];
-    const int* iv = inv + (size_t)f * P; const float* g = gout + (size_t)j * 3 * P;
+                               const float* __restrict__ gimg, const fx_t* __restrict__ gpre, float pre_scale, int b, int j0,
+                               float* __restrict__ gfeat, int P, size_t K) {
+    const int j = j0 + blockIdx.y, f = fidx[j];
+    const int* iv = inv + (size_t)f * P;
+    const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
+    const fx_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         size_t id = (size_t)iv[p];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = feat[c * K + id] * SH_C0 + 0.5f, gc = g[c * P + p];
-            if (v >= 0.f && v <= 1.f && gc != 0.f) atomicAdd(gfeat + c * K + id, gc * SH_C0);
+            float v = feat[c * K + id] * SH_C0 + 0.5f, gc = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
+            if (v >= 0.f && v <= 1.f && gc != 0.f) {
+                if (ATOMIC) atomicAdd(gfeat + c * K + id, gc * SH_C0);
+                else gfeat[c * K + id] += gc * SH_C0;
+            }
         }
     }
+}
+// Are the ids of every frame distinct?  Per frame: every pixel writes its index into scratch[id], then checks that it is still there.
+__global__ void k_ids_mark(const int* __restrict__ inv, int P, int* __restrict__ scratch) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) scratch[inv[p]] = p;
+}
+__global__ void k_ids_check(const int* __restrict__ inv, int P, const int* __restrict__ scratch, int* __restrict__ flag) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x)
+        if (scratch[inv[p]] != p) *flag = 0;
 }
 
 // ---------------------------------------------------------------- MS-SSIM
@@ -168,7 +213,7 @@ __global__ void k_pool2(const float* __restrict__ in, const int* __restrict__ fi
 // (d/d sigma12, d/d sigma1^2, d/d mu1-equivalent) the backward pass filters back.
 __global__ __launch_bounds__(256) void k_ssim_fwd(const float* __restrict__ X, const float* __restrict__ Y, int h, int w, int last,
                                                   float c1, float c2, Gauss11 G, float* __restrict__ mA, float* __restrict__ mB,
-                                                  float* __restrict__ mC, float* __restrict__ sums) {
+                                                  float* __restrict__ mC, fx_t* __restrict__ sums) {
     __shared__ float sx[TIH][TIW + 1], sy[TIH][TIW + 1];
     __shared__ float hz[5][TIH][TW];
     __shared__ float red[16];
@@ -217,13 +262,13 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(const float* __restrict__ X, c
         acc += val;
     }
     float r = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(sums + q, r);
+    if (threadIdx.x == 0) fx_add(sums + q, r, FX_SSIM);
 }
 // per-plane product over levels, loss value and upstream scalars (loss_utils.py:196-211).
 // sums: [4][planes] (levels 1..4 are computed, level 0 is the constant 1 of start_level=1);
 // cnt[l] = valid pixels of level l.  scal[l][q] = d(loss)/d(sum_l[q]); loss_out += lambda*(1-mean msssim)
 struct Cnt4 { float c[4]; };
-__global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, int planes_norm, Cnt4 cn, float lambda,
+__global__ void k_msssim_finalize(const fx_t* __restrict__ sums, int planes, int planes_norm, Cnt4 cn, float lambda,
                                   float* __restrict__ scal, float* __restrict__ loss_out) {
     // planes_norm: the plane count the mean runs over (== planes on one GPU; the GLOBAL batch*3 when the mini-batch is split over ranks:
     // the per-rank terms then add up to the global loss and the gradients carry the global 1/planes).
@@ -232,7 +277,7 @@ __global__ void k_msssim_finalize(const float* __restrict__ sums, int planes, in
     float tot = 0.f;
     for (int q = threadIdx.x; q < planes; q += blockDim.x) {
         float v[4], prod = 1.f;
-        for (int l = 0; l < 4; ++l) { v[l] = fmaxf(sums[l * planes + q] / cn.c[l], 0.f); prod *= powf(v[l], wgt[l]); }
+        for (int l = 0; l < 4; ++l) { v[l] = fmaxf(fx_get(sums[l * planes + q], 1.f / FX_SSIM) / cn.c[l], 0.f); prod *= powf(v[l], wgt[l]); }
         tot += prod;
         for (int l = 0; l < 4; ++l)
             scal[l * planes + q] = v[l] > 0.f ? -lambda / (float)planes_norm * prod * wgt[l] / v[l] / cn.c[l] : 0.f;
@@ -282,7 +327,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(const float* __restrict__ X, c
 // gimg[p] = avgpool-backward(grad of level 1) + L1-photometric grad + TV grad; sums -> acc[0..2]
 __global__ void k_pixel_losses(const float* __restrict__ img, const float* __restrict__ tgt, const int* __restrict__ idx,
                                const float* __restrict__ g1, int h1, int w1, int H, int W, float coef_l1, float coef_tvh,
-                               float coef_tvw, float* __restrict__ gimg, float* __restrict__ acc) {
+                               float coef_tvw, float* __restrict__ gimg, fx_t* __restrict__ acc) {
     __shared__ float red[16];
     const int q = blockIdx.y, P = H * W;
     const float* x = img + (size_t)q * P;
@@ -307,21 +352,22 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
     }
     float r0 = block_sum(s_l1, red), r1 = block_sum(s_h, red), r2 = block_sum(s_w, red);
     if (threadIdx.x == 0) {
-        float* a = acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4;     // spread same-address atomics over slots
-        if (coef_l1 != 0.f) atomicAdd(a + 0, r0);
-        if (coef_tvh != 0.f) { atomicAdd(a + 1, r1); atomicAdd(a + 2, r2); }
+        fx_t* a = acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4;     // spread same-address atomics over slots
+        if (coef_l1 != 0.f) fx_add(a + 0, r0, FX_ACC);
+        if (coef_tvh != 0.f) { fx_add(a + 1, r1, FX_ACC); fx_add(a + 2, r2, FX_ACC); }
     }
 }
 // flow-consistency term (generate.py:420-427): warp(pre)*m vs img*m, fwd + bwd fused.
-// images = cat[0..b), pre = cat[b..2b); gcat same layout.  gimg gets '-=' (owner pixel), gpre atomics.
+// images = cat[0..b), pre = cat[b..2b).  gimg [b,3,P] gets '-=' (owner pixel); the scatter into the previous frame's gradient goes to
+// gpre [b,3,P] in fixed point, UNSCALED (sign * mask * bicubic weight; the consumer multiplies by scale / FX_FLOW): integer atomics.
 __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
-                            const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gcat,
-                            float* __restrict__ acc) {
+                            const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
+                            fx_t* __restrict__ gpre, fx_t* __restrict__ acc) {
     __shared__ float red[16];
     const int j = blockIdx.y, f = idx[j], P = H * W;
     if (f == 0) return;  // valid = idx > 0
     const float* img = cat + (size_t)j * 3 * P; const float* pre = cat + (size_t)(b + j) * 3 * P;
-    float* gi = gcat + (size_t)j * 3 * P; float* gp = gcat + (size_t)(b + j) * 3 * P;
+    float* gi = gimg + (size_t)j * 3 * P; fx_t* gp = gpre + (size_t)j * 3 * P;
     const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
@@ -349,8 +395,8 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
         for (int c = 0; c < 3; ++c) {
             float d = wv[c] * m - img[c * P + pc] * m;
             s += fabsf(d);
-            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m * scale;      // 0 on dead lanes (m = 0)
-            if (live) gi[c * P + p] -= gw[c];
+            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m;              // 0 on dead lanes (m = 0); unscaled
+            if (live) gi[c * P + p] -= gw[c] * scale;
         }
         // Scatter of d(loss)/d(warped) into the pre-image gradient: 16 taps x 3 channels per pixel.  Neighbouring pixels of a row whose taps
         // share the integer offset (dx, dy) hit neighbouring cells: lane l's tap i and lane l+i's tap 0 are the SAME cell, so the four
@@ -380,23 +426,25 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
                 const float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
                 const float sum = v0 + (up[1] ? u1 : 0.f) + (up[2] ? u2 : 0.f) + (up[3] ? u3 : 0.f);
                 if (!rowok) continue;
-                float* row = gp + (size_t)c * P + (size_t)yy * W;
-                if (t.x0 >= 0 && t.x0 < W && sum != 0.f) atomicAdd(row + t.x0, sum);
-                if (!dn[1] && v1 != 0.f && t.x0 + 1 >= 0 && t.x0 + 1 < W) atomicAdd(row + t.x0 + 1, v1);
-                if (!dn[2] && v2 != 0.f && t.x0 + 2 >= 0 && t.x0 + 2 < W) atomicAdd(row + t.x0 + 2, v2);
-                if (!dn[3] && v3 != 0.f && t.x0 + 3 >= 0 && t.x0 + 3 < W) atomicAdd(row + t.x0 + 3, v3);
+                fx_t* row = gp + (size_t)c * P + (size_t)yy * W;
+                if (t.x0 >= 0 && t.x0 < W && sum != 0.f) fx_add(row + t.x0, sum, FX_FLOW);
+                if (!dn[1] && v1 != 0.f && t.x0 + 1 >= 0 && t.x0 + 1 < W) fx_add(row + t.x0 + 1, v1, FX_FLOW);
+                if (!dn[2] && v2 != 0.f && t.x0 + 2 >= 0 && t.x0 + 2 < W) fx_add(row + t.x0 + 2, v2, FX_FLOW);
+                if (!dn[3] && v3 != 0.f && t.x0 + 3 >= 0 && t.x0 + 3 < W) fx_add(row + t.x0 + 3, v3, FX_FLOW);
             }
         }
     }
     float r = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4 + 3, r);
+    if (threadIdx.x == 0) fx_add(acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4 + 3, r, FX_ACC);
 }
 // loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
-__global__ void k_loss_finalize(float* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
+__global__ void k_loss_finalize(fx_t* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
                                 float c_tvh, float c_tvw, float* loss_out) {
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    fx_t t[4] = {0, 0, 0, 0};
     for (int sidx = 0; sidx < ACC_SLOTS; ++sidx)
-        for (int k = 0; k < 4; ++k) { a[k] += acc[sidx * 4 + k]; acc[sidx * 4 + k] = 0.f; }
+        for (int k = 0; k < 4; ++k) { t[k] += acc[sidx * 4 + k]; acc[sidx * 4 + k] = 0; }
+    float a[4];
+    for (int k = 0; k < 4; ++k) a[k] = fx_get(t[k], 1.f / FX_ACC);
     *loss_out = w_photo * (c_l1 * a[0] + *ms_term) + w_flow * a[3] * inv_cnt_flow + c_tvh * a[1] + c_tvw * a[2];
 }
 
@@ -410,14 +458,15 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
         p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
+template <bool ATOMIC>
 __global__ void k_scatter_accum(const float* __restrict__ img, const int* __restrict__ inv, float* __restrict__ sum,
-                                float* __restrict__ cnt, int P, size_t K) {
-    const int f = blockIdx.y;
+                                float* __restrict__ cnt, int P, size_t K, int f0) {
+    const int f = f0 + blockIdx.y;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         size_t id = inv[(size_t)f * P + p];
         const float* s = img + (size_t)f * 3 * P;
-        atomicAdd(sum + id, s[p]); atomicAdd(sum + K + id, s[P + p]); atomicAdd(sum + 2 * K + id, s[2 * P + p]);
-        atomicAdd(cnt + id, 1.f);
+        if (ATOMIC) { atomicAdd(sum + id, s[p]); atomicAdd(sum + K + id, s[P + p]); atomicAdd(sum + 2 * K + id, s[2 * P + p]); atomicAdd(cnt + id, 1.f); }
+        else { sum[id] += s[p]; sum[K + id] += s[P + p]; sum[2 * K + id] += s[2 * P + p]; cnt[id] += 1.f; }     // ids distinct within frame f
     }
 }
 __global__ void k_scatter_final(float* __restrict__ feat, const float* __restrict__ cnt, size_t K) {
@@ -458,16 +507,28 @@ int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, fl
     hipLaunchKernelGGL(k_adam, dim3(stream_grid((long)n, 256, 4)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
     TCL_LAUNCH_RET();
 }
-int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, hipStream_t st) {
+int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float* cnt, int n, int h, int w, size_t K, int ids_unique, hipStream_t st) {
     TCL_CHECK_ARG(img && inv && feat && cnt && K > 0);
     if (hipMemsetAsync(feat, 0, K * 12, st) != hipSuccess || hipMemsetAsync(cnt, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
-    hipLaunchKernelGGL(k_scatter_accum, pgrid(h * w, n), dim3(256), 0, st, img, inv, feat, cnt, h * w, K);
+    if (ids_unique)          // frame after frame: conflict-free inside a frame, fixed order across frames (bit-reproducible sums)
+        for (int f = 0; f < n; ++f) hipLaunchKernelGGL(k_scatter_accum<false>, pgrid(h * w, 1), dim3(256), 0, st, img, inv, feat, cnt, h * w, K, f);
+    else hipLaunchKernelGGL(k_scatter_accum<true>, pgrid(h * w, n), dim3(256), 0, st, img, inv, feat, cnt, h * w, K, 0);
     hipLaunchKernelGGL(k_scatter_final, dim3(stream_grid((long)K * 3, 256, 4)), dim3(256), 0, st, feat, cnt, K);
+    TCL_LAUNCH_RET();
+}
+int tcl_track_ids_unique(const int* unq_inv, int N, int H, int W, size_t K, int* scratch, int* result, hipStream_t st) {
+    TCL_CHECK_ARG(unq_inv && scratch && result && N > 0 && H > 0 && W > 0 && K > 0);
+    const int one = 1, P = H * W;
+    if (hipMemcpyAsync(result, &one, 4, hipMemcpyHostToDevice, st) != hipSuccess) return TCL_ELAUNCH;
+    for (int f = 0; f < N; ++f) {
+        hipLaunchKernelGGL(k_ids_mark, pgrid(P, 1), dim3(256), 0, st, unq_inv + (size_t)f * P, P, scratch);
+        hipLaunchKernelGGL(k_ids_check, pgrid(P, 1), dim3(256), 0, st, unq_inv + (size_t)f * P, P, scratch, result);
+    }
     TCL_LAUNCH_RET();
 }
 
 // workspace carve for the MS-SSIM chain over `planes` planes of h x w
-struct MsWs { float *X[5], *Y[5], *mA[5], *mB[5], *mC[5], *gX[5], *sums, *scal, *cnt, *term; int h[5], w[5]; size_t bytes; };
+struct MsWs { float *X[5], *Y[5], *mA[5], *mB[5], *mC[5], *gX[5], *scal, *cnt, *term; fx_t* sums; int h[5], w[5]; size_t bytes; };
 static MsWs carve_ms(char* base, int planes, int h, int w) {
     MsWs W; memset(&W, 0, sizeof(W));
     size_t off = 0;
@@ -478,7 +539,7 @@ static MsWs carve_ms(char* base, int planes, int h, int w) {
         size_t n = (size_t)planes * W.h[l] * W.w[l], no = (size_t)planes * (W.h[l] - HALO) * (W.w[l] - HALO);
         W.X[l] = take(n); W.Y[l] = take(n); W.gX[l] = take(n); W.mA[l] = take(no); W.mB[l] = take(no); W.mC[l] = take(no);
     }
-    W.sums = take((size_t)4 * planes); W.scal = take((size_t)4 * planes); W.cnt = take(4); W.term = take(1);
+    W.sums = (fx_t*)take((size_t)8 * planes); W.scal = take((size_t)4 * planes); W.cnt = take(4); W.term = take(1);
     W.bytes = off;
     return W;
 }
@@ -493,7 +554,7 @@ static int msssim_chain(const float* X, const float* Y, const int* yidx, int pla
     for (int l = 1; l < 5; ++l) if (W.h[l] < 11 || W.w[l] < 11) return TCL_EINVAL;
     Cnt4 cn;
     for (int l = 1; l < 5; ++l) cn.c[l - 1] = (float)(W.h[l] - HALO) * (float)(W.w[l] - HALO);
-    if (hipMemsetAsync(W.sums, 0, (size_t)4 * planes * 4, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(W.sums, 0, (size_t)4 * planes * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     for (int l = 1; l < 5; ++l) {
         dim3 g(cdiv((long)W.h[l] * W.w[l], 256) > 512 ? 512 : cdiv((long)W.h[l] * W.w[l], 256), planes);
         hipLaunchKernelGGL(k_pool2, g, dim3(256), 0, st, l == 1 ? X : W.X[l - 1], (const int*)nullptr, W.X[l], W.h[l - 1], W.w[l - 1], W.h[l], W.w[l]);
@@ -521,7 +582,7 @@ int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, f
     if (rc) return rc;
     if (gradX) {
         hipLaunchKernelGGL(k_pixel_losses, pgrid(h * w, planes), dim3(256), 0, st, X, (const float*)nullptr, (const int*)nullptr, W.gX[1],
-                           W.h[1], W.w[1], h, w, 0.f, 0.f, 0.f, gradX, W.term);
+                           W.h[1], W.w[1], h, w, 0.f, 0.f, 0.f, gradX, (fx_t*)nullptr);
     }
     if (hipMemcpyAsync(value, W.term, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TCL_ELAUNCH;
     TCL_LAUNCH_RET();
@@ -529,22 +590,24 @@ int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, f
 
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st) {
     TCL_CHECK_ARG(x && value && grad && ws16 && b > 0);
-    float* acc = (float*)ws16;
-    if (hipMemsetAsync(acc, 0, ACC_SLOTS * 16 + 4, st) != hipSuccess) return TCL_ELAUNCH;
+    fx_t* acc = (fx_t*)ws16;                                                  // [ACC_SLOTS][4] fixed-point cells, then one zero float
+    float* zero = (float*)(acc + ACC_SLOTS * 4);
+    if (hipMemsetAsync(acc, 0, ACC_SLOTS * 4 * sizeof(fx_t) + 4, st) != hipSuccess) return TCL_ELAUNCH;
     float ch = weight * 2.f / ((float)c * (h - 1) * w) / b, cw = weight * 2.f / ((float)c * h * (w - 1)) / b;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(h * w, b * c), dim3(256), 0, st, x, (const float*)nullptr, (const int*)nullptr,
                        (const float*)nullptr, 0, 0, h, w, 0.f, ch, cw, grad, acc);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, acc, acc + ACC_SLOTS * 4 /* a zero */, 0.f, 0.f, 0.f, 0.f, ch, cw, value);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, acc, zero, 0.f, 0.f, 0.f, 0.f, ch, cw, value);
     TCL_LAUNCH_RET();
 }
 
 // ---- whole-stage drivers -------------------------------------------------------------------
-struct StageWs { float *cat, *gcat, *acc; int* cidx; MsWs ms; size_t bytes; };
+struct StageWs { float *cat, *gimg; fx_t *gpre, *acc, *efx; int* cidx; MsWs ms; size_t bytes; };
 static StageWs carve_stage(char* base, int b, int h, int w) {
     StageWs S; size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
     size_t P = (size_t)h * w;
-    S.cat = (float*)take(2 * b * 3 * P * 4); S.gcat = (float*)take(2 * b * 3 * P * 4); S.acc = (float*)take(ACC_SLOTS * 16);
+    S.cat = (float*)take(2 * b * 3 * P * 4); S.gimg = (float*)take(b * 3 * P * 4); S.gpre = (fx_t*)take(b * 3 * P * sizeof(fx_t));
+    S.acc = (fx_t*)take(ACC_SLOTS * 4 * sizeof(fx_t)); S.efx = (fx_t*)take((size_t)2 * b * 12 * sizeof(fx_t));
     S.cidx = (int*)take(2 * b * 4);
     size_t msb = carve_ms(nullptr, b * 3, h, w).bytes;
     char* mp = take(msb);
@@ -573,23 +636,28 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
     const size_t P = (size_t)H * W;
     const int b = b_loc;
     S.cidx = const_cast<int*>(d_cidx);
-    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 4 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     hipLaunchKernelGGL(k_apply_exposure, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.cat, (int)P);
     const float wp = 1.f - lambda_flow, c_l1 = wp * (1.f - lambda_dssim) / ((float)b_glob * 3 * P);  // (1-lf) folded in
     int rc = msssim_chain(S.cat, edited, S.cidx, b * 3, H, W, wp * lambda_dssim, S.ms, true, st, b_glob * 3);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, edited, S.cidx, S.ms.gX[1], S.ms.h[1], S.ms.w[1], H, W,
-                       c_l1, 0.f, 0.f, S.gcat, S.acc);
-    if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+                       c_l1, 0.f, 0.f, S.gimg, S.acc);
+    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.efx, 0, (size_t)2 * b * 12 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
-    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
-    hipLaunchKernelGGL(k_exposure_bwd, pgrid(P, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gcat, g, (int)P);
+    const float fscale = lambda_flow * inv_cnt;
+    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc);
+    // 64 blocks per row (each block ends in 12 block-wide sums + 12 atomics: with the P / 1024-pixel blocks of the other kernels this was the
+    // slowest kernel of stage 1), partial sums in fixed point, rows added to the gradient in order
+    hipLaunchKernelGGL(k_exposure_bwd, dim3(64, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gimg, S.gpre, fscale / FX_FLOW, b, S.efx, (int)P);
+    hipLaunchKernelGGL(k_expo_fin, dim3(1), dim3(64), 0, st, S.efx, S.cidx, 2 * b, g);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, c_l1, lambda_flow, inv_cnt, 0.f, 0.f, loss_part);
     TCL_LAUNCH_RET();
 }
 
 int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
-                           const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                           int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
                            float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st) {
     TCL_CHECK_ARG(target && flows && masks && unq_inv && d_cidx && feat && g && loss_part && ws);
     TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_loc <= 64 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160 && K > 0);
@@ -597,18 +665,22 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     const size_t P = (size_t)H * W;
     const int b = b_loc;
     S.cidx = const_cast<int*>(d_cidx);
-    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 16, st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 4 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
     // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
     int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st, b_glob * 3);
     if (rc) return rc;
     float ch = lambda_tv * 2.f / (3.f * (H - 1) * W) / b_glob, cw = lambda_tv * 2.f / (3.f * H * (W - 1)) / b_glob;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, (const float*)nullptr, S.cidx, S.ms.gX[1], S.ms.h[1],
-                       S.ms.w[1], H, W, 0.f, ch, cw, S.gcat, S.acc);
-    if (hipMemsetAsync(S.gcat + (size_t)b * 3 * P, 0, (size_t)b * 3 * P * 4, st) != hipSuccess) return TCL_ELAUNCH;
+                       S.ms.w[1], H, W, 0.f, ch, cw, S.gimg, S.acc);
+    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
-    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, lambda_flow * inv_cnt, S.gcat, S.acc);
-    hipLaunchKernelGGL(k_codebook_bwd, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gcat, g, (int)P, K);
+    const float fscale = lambda_flow * inv_cnt;
+    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc);
+    if (ids_unique)          // one cat row per launch, in order: conflict-free read-modify-write of the rows' gradients, no atomics
+        for (int j = 0; j < 2 * b; ++j)
+            hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale / FX_FLOW, b, j, g, (int)P, K);
+    else hipLaunchKernelGGL(k_codebook_bwd<true>, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale / FX_FLOW, b, 0, g, (int)P, K);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, loss_part);
     TCL_LAUNCH_RET();
 }
@@ -643,7 +715,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
 
 // Stage 2 (generate.py:453-533).  feat/g/m/v: channel-planar [3,K] device (feat initialised by tcl_scatter_mean_rgb2sh, others 0).
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
-                          size_t K, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
+                          size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
                           float lambda_tv, float* feat, float* g, float* m, float* v, float* losses, float* images_out, void* ws,
                           hipStream_t st) {
     TCL_CHECK_ARG(target && flows && masks && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
@@ -655,7 +727,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         int b = 0, nvalid = 0;
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
-        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim,
+        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, ids_unique, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim,
                                         lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
         if (rc) return rc;
         rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);

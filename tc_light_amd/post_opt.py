@@ -199,6 +199,17 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
     return out, expo, losses
 
 
+def track_ids_unique(inv, n, h, w, k, scratch=None):
+    """1 when the track ids of every frame are pairwise distinct -- true of get_flowid's ids (a pixel inherits ONE id or gets a fresh one,
+    utils/flow_utils.py:56-93).  Stage 2 then accumulates codebook gradients frame by frame without atomics (bit-reproducible); 0 (any other
+    id layout) takes the float-atomic kernels.  One device-to-host read per run."""
+    if scratch is None:
+        scratch = torch.empty(k, dtype=torch.int32, device=inv.device)
+    res = torch.zeros(1, dtype=torch.int32, device=inv.device)
+    lib().tcl_track_ids_unique(inv, n, h, w, k, scratch, res, stream())
+    return int(res.item())
+
+
 def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature_lr=0.05, lambda_dssim=0.2,
                                lambda_flow=0.8, lambda_tv=0.05, k=None, dist=None):
     """generate.py:453-533.  unq_inv: [N*H*W] integer tensor on the device.  Returns (images, features_dc, losses).
@@ -217,14 +228,15 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
     flat = torch.zeros(npad, device=dev)
     feat = flat[:3 * k].view(3, k)                      # channel-planar codebook (features_dc.t())
     cnt = torch.empty(k, device=dev)
-    L.tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, stream())
+    uniq = track_ids_unique(inv, n, h, w, k, scratch=cnt.view(torch.int32))
+    L.tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, uniq, stream())
     del cnt
     out = torch.empty_like(ed)
     if world == 1:
         g, m, v = (torch.zeros_like(feat) for _ in range(3))
         losses = torch.zeros(max(len(sched), 1), device=dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
-        L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, sched.ctypes.data, d_cat,
+        L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, uniq, sched.ctypes.data, d_cat,
                                 len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
                                 losses, out, ws, stream())
         losses = losses[:len(sched)]
@@ -236,7 +248,7 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
         lr = feature_lr * batch_size / n                # generate.py:474
 
         def grad_fn(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
-            L.tcl_unique_tensor_grad(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, lcat[it], len(slots), b_glob, nvalid,
+            L.tcl_unique_tensor_grad(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, uniq, lcat[it], len(slots), b_glob, nvalid,
                                      lambda_dssim, lambda_flow, lambda_tv, p_full, g_full, loss_out, ws, stream())
 
         def adam_fn(it, p, gg, m, v):

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -144,10 +145,24 @@ def _stage_inputs():
     return d, inv, k, sched
 
 
-def _stage_worker(rank, world, port, ret):
+def _stage_worker(rank, world, port, ret, rccl_branch=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
+    if rccl_branch:
+        # Backend-name shim: parallel.Dist takes its RCCL branch (one reduce_scatter_tensor instead of all_reduce + slice).  gloo has no
+        # reduce_scatter, so the collective itself is stood in for by its definition on top of all_reduce; what the test then pins is the
+        # branch's own arithmetic: shard sizes, the (full, out) argument order, in-place semantics, the zeroing of g_full afterwards.
+        calls = []
+
+        def reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM):
+            assert op == dist.ReduceOp.SUM and full.numel() == world * out.numel() and out.is_contiguous()
+            tmp = full.clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            out.copy_(tmp[rank * out.numel():(rank + 1) * out.numel()])
+            calls.append(out.numel())
+        dist.get_backend = lambda *a, **k: "nccl"
+        dist.reduce_scatter_tensor = reduce_scatter_tensor
     from oracle import path2 as O
     from tc_light_amd.hostlogic import expon_lr
     from tc_light_amd.parallel import Dist, distributed_adam_loop
@@ -184,17 +199,20 @@ def _stage_worker(rank, world, port, ret):
     def adam2(it, p, g, m, v):
         _adam(p, g, m, v, lr, 1e-15, it + 1)
     l2 = distributed_adam_loop(d, sched, flat, torch.zeros(npad), grad2, adam2, shard_state=True)
+    if rccl_branch:
+        assert calls == [npad // world] * len(sched), calls          # one reduce_scatter per stage-2 iteration, none in stage 1
     if rank == 0:
         ret.put(tuple(np.asarray(t.detach().cpu().numpy()) for t in (expo, l1, flat[:3 * k].view(k, 3).clone(), l2)))
     dist.destroy_process_group()
 
 
-def test_global_stage1_stage2_world2_equals_single_process():
+@pytest.mark.parametrize("rccl_branch", [False, True])
+def test_global_stage1_stage2_world2_equals_single_process(rccl_branch):
     from oracle import path2 as O
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, ret, rccl_branch)) for r in range(2)]
     for p in procs:
         p.start()
     expo, l1, feats, l2 = (torch.from_numpy(a) for a in ret.get())

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--epochs_exposure", type=int, default=35)
     ap.add_argument("--epochs", type=int, default=70)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_full", action="store_true", help="the FULL SURVEY 8(d) CPU sample (merged 4-frame xy chunk + yt chunk through the oracle "
+                    "UNet, 3 iterations of each optimiser stage at batch 16): minutes of host time instead of the default ~30 s sample")
     ap.add_argument("--no_extras", action="store_true", help="skip the figures reported beside the metric (configs[1] pass, flow estimation / matting)")
     ap.add_argument("--exclusive", action="store_true", help="one extra untimed pass with the matching chain on the main stream (flash kernel alone on the GPU)")
     ap.add_argument("--no_multi_axis", action="store_true")
@@ -52,11 +54,18 @@ def parse():
 
 
 def synth_inputs(n, H, W, lo, hi, dev, seed=12345):
-    """translated low-pass frames, analytic backward flow + noise, soft mask, track ids."""
+    """translated low-pass frames, analytic backward flow + noise, soft mask; the track ids (unq_inv, K) come from the engine's
+    own get_flowid on those frames / flows / masks (tc_light_amd/flow_ids.py <- utils/flow_utils.py:56-93), as SURVEY 8(d) config 5 asks --
+    untimed input preparation, like the flows themselves."""
     import synth
+    from tc_light_amd import flow_ids
     d = synth.video_clip(n, H, W, seed=seed)
-    inv, k = synth.track_ids(n, H, W, seed=3)
-    return (d["frames"][lo:hi].to(dev), d["past_flows"].to(dev), d["masks"].to(dev), inv.to(device=dev, dtype=torch.int32), k)
+    past, masks = d["past_flows"].to(dev), d["masks"].to(dev)
+    fwd = -past.roll(-1, 0)                                    # forward flow of frame i = minus the backward flow of frame i+1 (pure translation)
+    fwd[-1] = 0
+    ids, k = flow_ids.get_flowid(d["frames"].to(dev), fwd, masks)
+    del fwd
+    return (d["frames"][lo:hi].to(dev), past, masks, ids.reshape(-1), k)
 
 
 def producer_timings(frames, dev):
@@ -91,47 +100,81 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sd_unet, H, W, n_frames, flops_path1, cfg):
+def _best_threads(sd_unet):
+    """torch CPU kernels do not scale to every logical CPU of the GPU hosts: time a small UNet call at 64 / 128 / all threads, keep the best."""
+    from oracle import sd15 as OS
+    ncpu = os.cpu_count() or 1
+    g = np.random.default_rng(1)
+    x = torch.from_numpy(g.standard_normal((2, 8, 24, 40)).astype(np.float32))
+    text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32))
+    best, tried = None, {}
+    for nt in sorted({min(64, ncpu), min(128, ncpu), ncpu}):
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            OS.unet_forward(sd_unet, x, 801.0, text, None)
+            t0 = time.perf_counter()
+            OS.unet_forward(sd_unet, x, 801.0, text, None)
+        tried[nt] = time.perf_counter() - t0
+        if best is None or tried[nt] < tried[best]:
+            best = nt
+    torch.set_num_threads(best)
+    return best, tried
+
+
+def cpu_baseline(sd_unet, H, W, n_frames, flops_path1, cfg, full=False):
     """The oracle ("port": oracle/sd15.py + oracle/path2.py, the CPU restatement of the reference's PyTorch path) timed on this host's cores
-    on a bounded sample of THIS workload (cut to fit the ~10-30 s the harness allows): at the FULL latent resolution one
-    xy-plane UNet call on one frame (batch 2 = uncond + cond, L = 154) and one yt-plane call on one latent column of a 64-frame window
-    (L = 77), and at the FULL image resolution one iteration each of stage 1 and stage 2 on a 2-frame mini-batch.  Extrapolated by work:
-    path 1 = the pass's algorithmic UNet FLOPs / the measured CPU FLOP rate; path 2 = iterations x measured seconds per iteration scaled
-    from 2 to `batch_size` frames.  VAE time is left out (in the CPU's favour)."""
+    on a bounded sample of THIS workload, thread count = the best of 64 / 128 / all logical CPUs on a probe call (printed).
+    Default sample (~30 s, what the harness allows): at the FULL latent resolution one xy-plane UNet call on one frame (batch 2 = uncond +
+    cond, L = 154) and one yt-plane call on one latent column of a 64-frame window (L = 77); at the FULL image resolution one iteration
+    each of stage 1 and stage 2 on a 4-frame mini-batch, scaled to `batch_size`.
+    full=True (--cpu_full): SURVEY 8(d)'s sample as written -- one MERGED 4-frame xy chunk and one 4-column yt chunk through the oracle UNet
+    with the oracle's VidToMe, 3 iterations of each stage at batch 16.  Minutes of host time.
+    Extrapolated by work: path 1 = the pass's algorithmic UNet FLOPs / the measured CPU FLOP rate; path 2 = iterations x seconds per
+    iteration.  VAE time is left out (in the CPU's favour)."""
     from oracle import path2 as O2
     from oracle import sd15 as OS
     import synth
     ncpu = os.cpu_count() or 1
-    cores = min(ncpu, 64)             # torch CPU kernels stop scaling (and oversubscribe) beyond this on the GPU hosts
-    torch.set_num_threads(cores)
+    cores, tried = _best_threads(sd_unet)
     h, w = H // 8, W // 8
     g = np.random.default_rng(0)
     meas = []
+    F = 4 if full else 1
     for (ph, pw, L) in ((h, w, 154), (min(64, n_frames), h, 77)):
-        x = torch.from_numpy(g.standard_normal((2, 8, ph, pw)).astype(np.float32))
+        x = torch.from_numpy(g.standard_normal((2 * F, 8, ph, pw)).astype(np.float32))
         text = torch.from_numpy(g.standard_normal((2, L, 768)).astype(np.float32))
+        tome = None
+        if full:
+            import e2e_oracle as E
+            tc = E.ComputedToMe([(F, int(g.integers(0, 4)), 0.7)])       # the oracle decides its own merges (no bank: first chunk of a step)
+            tc.next_chunk()
+            tome = tc.hook((ph, pw))
         t0 = time.perf_counter()
         with torch.no_grad():
-            OS.unet_forward(sd_unet, x, 801.0, text, None)
-        meas.append((unet_flops_unmerged(2, ph, pw, L), time.perf_counter() - t0))
+            OS.unet_forward(sd_unet, x, 801.0, text, tome)
+        meas.append((unet_flops_unmerged(2 * F, ph, pw, L), time.perf_counter() - t0))
     cpu_rate = sum(f for f, _ in meas) / sum(t for _, t in meas)
-    d = synth.video_clip(3, H, W, seed=1)
-    inv, _ = synth.track_ids(3, H, W, seed=3)
-    bts = [torch.tensor([1, 2])]
+    bsz, its = (cfg["batch_size"], 3) if full else (4, 1)
+    d = synth.video_clip(bsz + 1, H, W, seed=1)
+    inv, _ = synth.track_ids(bsz + 1, H, W, seed=3)
+    bts = [torch.arange(1, bsz + 1)] * its
     t0 = time.perf_counter()
-    O2.exposure_align(d["edited"], d["past_flows"], d["masks"], bts, 1, 2)
-    t_it1 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]
+    O2.exposure_align(d["edited"], d["past_flows"], d["masks"], bts, 1, bsz)
+    t_it1 = (time.perf_counter() - t0) / its / bsz * cfg["batch_size"]
     t0 = time.perf_counter()
-    O2.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, 2)
-    t_it2 = (time.perf_counter() - t0) / 2 * cfg["batch_size"]
+    O2.unique_tensor_optimization(d["edited"], inv, d["past_flows"], d["masks"], bts, bsz)
+    t_it2 = (time.perf_counter() - t0) / its / bsz * cfg["batch_size"]
     per_epoch = -(-n_frames // cfg["batch_size"])
     total = flops_path1 / cpu_rate + per_epoch * (cfg["epochs_exposure"] * t_it1 + cfg["epochs"] * t_it2)
     return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port", host_cpu=_cpu_model(), host_logical_cpus=ncpu,
-                sample=f"oracle UNet forward at full latent resolution: xy plane {w}x{h} on 1 frame ({meas[0][0] / 1e12:.2f} TFLOP in {meas[0][1]:.1f} s) + yt "
-                       f"plane {h}x{min(64, n_frames)} on 1 column ({meas[1][0] / 1e12:.2f} TFLOP in {meas[1][1]:.1f} s) = {cpu_rate / 1e12:.3f} TFLOP/s on {cores} "
-                       f"threads; oracle stage-1 / stage-2 iteration on a 2-frame batch at {W}x{H} ({t_it1:.1f} / {t_it2:.1f} s per {cfg['batch_size']}-frame "
-                       f"iteration); extrapolated: {flops_path1 / 1e15:.2f} PFLOP of UNet work / CPU rate + {per_epoch * cfg['epochs_exposure']} + "
-                       f"{per_epoch * cfg['epochs']} optimiser iterations (VAE left out)")
+                threads_tried={str(k): round(v, 3) for k, v in tried.items()},
+                sample=f"{'FULL SURVEY 8(d) sample' if full else 'bounded sample'}: oracle UNet forward at full latent resolution: xy plane {w}x{h} on "
+                       f"{F} frame(s){' with VidToMe merging' if full else ''} ({meas[0][0] / 1e12:.2f} TFLOP unmerged-equivalent in {meas[0][1]:.1f} s) + yt "
+                       f"plane {h}x{min(64, n_frames)} on {F} column(s) ({meas[1][0] / 1e12:.2f} TFLOP in {meas[1][1]:.1f} s) = {cpu_rate / 1e12:.3f} TFLOP/s on {cores} "
+                       f"threads (probe: {tried}); oracle stage-1 / stage-2: {its} iteration(s) on a {bsz}-frame batch at {W}x{H} ({t_it1:.1f} / {t_it2:.1f} s per "
+                       f"{cfg['batch_size']}-frame iteration); extrapolated: {flops_path1 / 1e15:.2f} PFLOP of UNet work / CPU rate + "
+                       f"{per_epoch * cfg['epochs_exposure']} + {per_epoch * cfg['epochs']} optimiser iterations (VAE left out).  Config 1 in full on the oracle: "
+                       f"tests/test_gpu_e2e.py prints it (129 s for denoise + VAE on 64 threads in round 2)")
 
 
 def unet_flops_unmerged(B, h, w, L):
@@ -320,8 +363,8 @@ def main():
                                       else " (NOT the BASELINE workload: non-default flags)"),
                        "step": "one denoising step of the end-to-end pass; the timed region is the whole pass (VAE encode/decode and both optimiser stages included)",
                        "frames_total": n_total, "passes_timed": passes, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
-                       "parallelism": (f"frames sharded x{world} (38/37 per rank at 300), yt-plane all-gather + all-reduce per step, global stage-1/2 "
-                                       f"(gradient all-reduce / reduce-scatter)") if world > 1 else "single GPU",
+                       "parallelism": (f"frames sharded x{world} (38/37 per rank at 300), yt-plane all-gather + all-reduce per step, decoded frames all-gathered, "
+                                       f"stage 1/2 replicated on every rank (no collective; bit-reproducible)") if world > 1 else "single GPU",
                        "gemm_tile_table_entries_loaded": table_entries},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
             "pass_seconds": dt / passes, "input_synthesis_seconds": round(t_setup, 1),
@@ -332,6 +375,22 @@ def main():
                          "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": unet.flops / 1e12,
                          "how": "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"},
         }
+        if a.epochs > 0 and info["timing"]["stage2"] > 0:
+            # Path 2's dominant kernel group: one stage-2 iteration (gather, losses, codebook gradient, dense Adam).  Algorithmic HBM bytes per
+            # iteration: (56 + 48 + 24) b P for the mini-batch + 84 K for the dense Adam stream; time = the stage's wall clock inside
+            # the timed pass / its iterations (whole-stage driver: no host sync between iterations; scatter-mean init and the final gather included).
+            it2 = a.epochs * (-(-n_total // cfg["batch_size"]))
+            by2 = (56 + 48 + 24) * cfg["batch_size"] * H * W + 84 * int(K)
+            t_it = info["timing"]["stage2"] / it2
+            it1 = a.epochs_exposure * (-(-n_total // cfg["batch_size"]))
+            res["roofline_path2"] = {"bound": "hbm", "kernel": "stage-2 iteration (unique-tensor optimisation: codebook gather, MS-SSIM / TV / flow losses + "
+                                     "gradients, frame-ordered codebook gradient, dense Adam over all K rows)", "achieved": by2 / t_it / 1e9, "peak": 8000.0,
+                                     "unit": "GB/s", "frac": by2 / t_it / 8e12, "traffic": None, "iterations": it2, "ms_per_iteration": t_it * 1e3,
+                                     "algorithmic_bytes_per_iteration": by2,
+                                     "stage1": {"ms_per_iteration": info["timing"]["stage1"] / max(it1, 1) * 1e3, "iterations": it1,
+                                                "achieved": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 1e9,
+                                                "frac": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 8e12},
+                                     "how": "phase wall clock of the timed pass / iterations; bit-reproducible run to run (fixed-point accumulators)"}
         if len(prof) > 3 and prof[3][2] > 0:
             res["roofline"]["alone"] = flash_alone(prof[3], dev)
         if prof_ex and prof_ex[0] > 0:
@@ -360,7 +419,7 @@ def main():
                 res["configs1"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, flops_pass, cfg)
+                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, flops_pass, cfg, full=a.cpu_full)
             except Exception as e:  # the baseline must never sink the measurement
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

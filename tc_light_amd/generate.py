@@ -27,9 +27,15 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
     global_merge_ratio=0.5, global_rand=0.5, align_batch=True, max_downsample=2, noise_mode="same", alpha_t=0.0,
     final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
     lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345,
-    shard_post_opt=False,            # multi-GPU only.  False (default): ONE global exposure set / codebook over all frames, gradients meet in
-                                     # collectives (post_opt.py) -- the reference's semantics.  True: the collective-free
-                                     # approximation (each rank's frame block as a video of its own: tracks cut at the 7 block seams).
+    post_opt_mode="replicated",      # multi-GPU only: how stage 1 / stage 2 run once the decoded frames are all-gathered.
+                                     # "replicated" (default): every rank runs the WHOLE optimisation on all frames, no collective at all --
+                                     #   both stages are bound by streams that do not shrink with the mini-batch share (dense Adam over all K
+                                     #   rows, scatters), path 2 is bit-reproducible, so the replicas agree bit for bit and the result is the
+                                     #   one-GPU result.  "global": ONE parameter set with the mini-batch dealt over the ranks, gradients meet in
+                                     #   all_reduce / reduce_scatter (2 x 12 K bytes per stage-2 iteration over xGMI: slower than replication
+                                     #   from K ~ 1e7 up; kept for memory-bound cases).  "shard": the round-1 approximation, each rank's frame
+                                     #   block as a video of its own (tracks cut at the block seams) -- NOT the reference's result.
+    shard_post_opt=False,            # legacy spelling of post_opt_mode="shard"
     max_tokens_per_pass=1_500_000)   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split
 
 
@@ -174,7 +180,10 @@ class Generator:
         x = self.ddim_sample(self.init_noise.clone(), conds, conds_t, concat_conds)
         t2 = ev()
         clean_local = self.vae.decode_latents_batch(x, self.batch_size)
-        shard = d.world > 1 and c.shard_post_opt and c.apply_opt
+        mode = "shard" if c.shard_post_opt else str(c.post_opt_mode)
+        if mode not in ("replicated", "global", "shard"):
+            raise ValueError(f"post_opt_mode {mode!r}: expected replicated | global | shard")
+        shard = d.world > 1 and mode == "shard" and c.apply_opt
         lo, hi = d.range(self.n_total)
         if shard:
             # Opt-in approximation: stage 1/2 on this rank's frame block as a video of its own (its first frame has no predecessor, tracks
@@ -191,7 +200,8 @@ class Generator:
         losses1 = losses2 = None
         if c.apply_opt:
             N = clean.shape[0]
-            pd = None if shard else d                   # global mode: the ranks split every mini-batch and share one parameter set
+            pd = d if (mode == "global" and d.world > 1) else None      # global: the ranks split every mini-batch and share one parameter set;
+            #                                                           # replicated / shard: every rank optimises on its own (no collective)
             ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
             rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # global mode: the identical schedule on every rank
             s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)

@@ -6,7 +6,9 @@ The reference is single-GPU; the sharding is this engine's design (
     (concat_conds once per run), the (window, column-chunk) work items are dealt round-robin to the ranks, each rank writes
     its columns into a zero full-size noise tensor and ONE all-reduce(SUM) assembles it (every element has one writer);
   * stage 1/2 optimise ONE global parameter set (generate.py:472-533: one features_dc [K,3] over all frames): the decoded frames are
-    all-gathered once, the slots of every mini-batch are dealt to the ranks (`deal_slots`), each rank back-propagates its slots with the
+    all-gathered once.  Default ("replicated", generate.py DEFAULTS.post_opt_mode): every rank then runs the whole optimisation itself --
+    no collective; both stages are bound by streams that do not shrink with a rank's share of the mini-batch, and path 2 is bit-reproducible
+    so the replicas agree.  "global" mode: the slots of every mini-batch are dealt to the ranks (`deal_slots`), each rank back-propagates its slots with the
     GLOBAL normalisers, and the gradients meet in a collective before the Adam step (`distributed_adam_loop`): stage 1 all-reduces the
     [N,3,4] exposure gradient (14 KB); stage 2 reduce-scatters the dense [3,K] codebook gradient, every rank owns 1/world of the
     codebook's Adam state (p, m, v: the 84 B/row/iteration stream is cut by world) and the updated rows are all-gathered.  Loss

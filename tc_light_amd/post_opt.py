@@ -75,7 +75,7 @@ class _TV(torch.autograd.Function):
         b, c, h, w = x.shape
         val = torch.empty(1, dtype=F32, device=x.device)
         grad = torch.empty_like(x)
-        ws = torch.empty(256, dtype=F32, device=x.device)
+        ws = torch.empty(512, dtype=F32, device=x.device)          # 2 KiB: fixed-point loss accumulators
         lib().tcl_tv_loss(x, b, c, h, w, float(weight), val, grad, ws, stream())
         ctx.grad = grad
         return val[0]

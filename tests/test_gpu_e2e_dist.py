@@ -2,6 +2,7 @@
 each rank owns a GPU and the backend is RCCL) against one rank, same seeds, real UNet / VAE engines (the reference is single-GPU).
 
 What has to agree, and to what:
+  (stage 1 / 2 run "replicated" by default -- every rank optimises all frames, no collective -- and once more in "global" mode, run G)
   A. VidToMe OFF (no global-token bank, so a frame's noise prediction does not depend on which chunk it rides in): everything the sharding
      adds -- frame blocks, the yt-plane pass dealt over the ranks and re-assembled (two overlapping windows), the SDE noise drawn for all frames
      and sliced, decoded frames all-gathered, stage 1 / stage 2 with ONE global parameter set and global normalisers -- must reproduce the
@@ -38,7 +39,7 @@ def _inputs():
     return d, inv, k, conds, conds_t
 
 
-def _run(dist_obj, vidtome_on, seed=12345):
+def _run(dist_obj, vidtome_on, seed=12345, mode="replicated", tome_seed=None):
     """One Generator.__call__ on this process's frame block -> (latents after the loop, relit frames, losses 1, losses 2) as numpy."""
     from tc_light_amd import sd15
     from tc_light_amd.generate import Generator
@@ -48,10 +49,11 @@ def _run(dist_obj, vidtome_on, seed=12345):
     global _ENG
     if "_ENG" not in globals():
         _ENG = (sd15.random_state_dict(sd15.unet_param_shapes(), seed=1), sd15.random_state_dict(sd15.vae_param_shapes(), seed=2))
-    unet = UNetEngine(_ENG[0], "cuda", VidToMe("cuda", seed=seed, enabled=vidtome_on))
+    unet = UNetEngine(_ENG[0], "cuda", VidToMe("cuda", seed=seed if tome_seed is None else tome_seed, enabled=vidtome_on))
     vae = VAEEngine(_ENG[1], "cuda")
     d, inv, k, conds, conds_t = _inputs()
-    cfg = dict(n_timesteps=2, alpha_t=0.01, final_factor_t=0.01, win_size_t=10, epochs_exposure=2, epochs=2, batch_size=8, seed=seed)
+    cfg = dict(n_timesteps=2, alpha_t=0.01, final_factor_t=0.01, win_size_t=10, epochs_exposure=2, epochs=2, batch_size=8, seed=seed,
+               post_opt_mode=mode)
     gen = Generator(unet, vae, cfg, dist=dist_obj)
     lo, hi = gen.dist.range(N)
     keep = {}
@@ -71,8 +73,8 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tc_light_amd.parallel import Dist
     res = {}
-    for tag, on in (("A", False), ("B", True)):
-        r = _run(Dist(rank, world), on)
+    for tag, on, mode in (("A", False, "replicated"), ("G", False, "global"), ("B", True, "replicated")):
+        r = _run(Dist(rank, world), on, mode=mode)
         if rank == 0:
             res[tag] = r
     if rank == 0:
@@ -101,7 +103,7 @@ def test_two_ranks_run_the_whole_pass():
         assert p.exitcode == 0
     from tc_light_amd.parallel import Dist
     one = {tag: _run(Dist(), on) for tag, on in (("A", False), ("B", True))}
-    other = _run(Dist(), True, seed=777)          # a second one-rank run with other chunk / VidToMe draws: the scale of "another valid sample"
+    other = _run(Dist(), True, tome_seed=777)     # a second one-rank run, same noise, other VidToMe draws (randf / src-dst coin): the scale of "another valid sample"
     # ---- A: the sharded choreography reproduces the one-rank run
     la, oa, l1a, l2a = two["A"]
     lr, orr, l1r, l2r = one["A"]
@@ -110,12 +112,19 @@ def test_two_ranks_run_the_whole_pass():
           % (ra["latents"], ra["frames"], ra["loss1"], ra["loss2"]))
     assert np.isfinite(oa).all() and oa.shape == orr.shape == (N, 3, HH, WW)
     assert ra["latents"] < 5e-3 and ra["loss1"] < 2e-3 and ra["loss2"] < 2e-3, ra
+    # the same pass with stage 1 / 2 in "global" mode (mini-batch slots dealt over the ranks, gradients meeting in collectives) instead of the
+    # default replication: same latents (bit for bit: the denoise phase is identical), same loss trajectories
+    lg, og, l1g, l2g = two["G"]
+    assert np.array_equal(lg, la)
+    rg = dict(loss1=float(np.abs(l1g / l1r - 1).max()), loss2=float(np.abs(l2g / l2r - 1).max()), frames_vs_replicated=rel(og, oa))
+    print("[2 ranks, stage 1/2 global mode vs replicated] losses max rel diff %.2e / %.2e, relit frames rel-L2 %.2e" % (rg["loss1"], rg["loss2"], rg["frames_vs_replicated"]))
+    assert rg["loss1"] < 2e-3 and rg["loss2"] < 2e-3, rg
     # ---- B: per-rank bank chains -- measured distance, bounded by the distance between two one-rank samples
     lb, ob, _, _ = two["B"]
     l1b, o1b, _, _ = one["B"]
     lo_, oo, _, _ = other
     rb = dict(latents=rel(lb, l1b), frames=rel(ob, o1b), latents_other_seed=rel(lo_, l1b), frames_other_seed=rel(oo, o1b))
     print("[2 ranks vs 1, VidToMe on: per-rank chunk order + bank chains] rel-L2 latents %.2e, relit frames %.2e  (two one-rank runs with "
-          "different chunk / VidToMe draws: %.2e / %.2e)" % (rb["latents"], rb["frames"], rb["latents_other_seed"], rb["frames_other_seed"]))
+          "other VidToMe draws: %.2e / %.2e)" % (rb["latents"], rb["frames"], rb["latents_other_seed"], rb["frames_other_seed"]))
     assert np.isfinite(ob).all()
     assert rb["latents"] < 2.0 * max(rb["latents_other_seed"], 1e-2), rb

@@ -110,6 +110,35 @@ def test_stage1_stage2_vs_golden_and_oracle(ops, golden):
     assert diff.max() < 3 * 0.05 * bs / n * 0.2821 + 1e-4
 
 
+def test_stage1_stage2_bit_reproducible(ops):
+    """Round 3: every reduction of path 2 whose order the hardware picks accumulates in 64-bit fixed point, and codebook rows are summed
+    frame by frame without atomics (track ids are unique inside a frame) -- so two runs of stage 1 + stage 2 on the same inputs give the SAME
+    BITS: exposures, losses, codebook, relit frames.  (Before: float atomics; the two runs ended 1e-2 apart after a full schedule, which is also
+    how far replicas of the optimiser on different ranks would drift.)  Ids that repeat inside a frame are detected and take the atomic path."""
+    from tc_light_amd import post_opt as P
+    d = synth.video_clip(6, 200, 224, seed=19, shift=(1.3, 0.6))           # fractional motion: the bicubic scatter has real collisions
+    inv, k = synth.track_ids(6, 200, 224, seed=4)
+    bts1 = synth.batches(6, 3, epochs=4, seed=2)
+    bts2 = synth.batches(6, 3, epochs=6, seed=3)
+    assert P.track_ids_unique(inv.cuda().int(), 6, 200, 224, k) == 1
+    runs = []
+    for _ in range(2):
+        ds = ops.OptDataset(d["edited"], d["past_flows"], d["masks"], device="cuda")
+        al, expo, l1 = ops.exposure_align(ds, bts1, epochs=4, batch_size=3)
+        out, feat, l2 = ops.unique_tensor_optimization(ds, inv.cuda(), bts2, batch_size=3, k=k)
+        torch.cuda.synchronize()
+        runs.append([t.detach().clone() for t in (al, expo, l1, out, feat.contiguous(), l2)])
+    for a, b, name in zip(runs[0], runs[1], ("aligned", "exposure", "losses 1", "relit", "codebook", "losses 2")):
+        assert torch.equal(a, b), name
+    # a frame that holds one id twice: detected, the float-atomic fallback still optimises (no bit-equality promised)
+    dup = inv.clone().view(6, -1)
+    dup[2, 5] = dup[2, 4]
+    assert P.track_ids_unique(dup.reshape(-1).cuda().int(), 6, 200, 224, k) == 0
+    ds = ops.OptDataset(d["edited"], d["past_flows"], d["masks"], device="cuda")
+    out_d, _, l2d = ops.unique_tensor_optimization(ds, dup.reshape(-1).cuda(), bts2[:3], batch_size=3, k=k)
+    assert torch.isfinite(out_d).all() and torch.isfinite(l2d).all()
+
+
 def test_full_size_properties(ops):
     """Config-(2)-sized checks through size-independent properties (the oracle would take minutes here)."""
     h, w = 720, 960
@@ -167,7 +196,9 @@ def test_load_data_composition_vs_oracle(ops):
     om = O.get_soft_mask_bwds(frames, fwd, past, alpha=0.5)
     oid = O.get_flowid(frames, fwd, om)
     oinv = O.voxelization_time_only(oid)
-    np.testing.assert_allclose(masks.cpu().numpy(), om.numpy(), atol=2e-5)
+    # (5e-5 here, 2e-5 on the golden clip: the occluder's hard edge sits on the steep part of sigmoid(-100 x), which amplifies the last-bit
+    #  differences of the bicubic warp 25-fold; measured 3.4e-5 on one pixel of 30 720)
+    np.testing.assert_allclose(masks.cpu().numpy(), om.numpy(), atol=5e-5)
     assert ((om - 0.5).abs() > 1e-3).all(), "the clip must not put a mask value on the 0.5 cut"
     assert np.array_equal(inv.cpu().numpy().astype(np.int64), oinv.numpy())
     assert k == int(oinv.max()) + 1 and k > 64 * 80 and k < 6 * 64 * 80     # tracks are re-used AND new ones appear

@@ -105,18 +105,22 @@ def _best_threads(sd_unet):
     from oracle import sd15 as OS
     ncpu = os.cpu_count() or 1
     g = np.random.default_rng(1)
-    x = torch.from_numpy(g.standard_normal((2, 8, 24, 40)).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((2, 8, 16, 24)).astype(np.float32))
     text = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32))
+    with torch.no_grad():
+        torch.set_num_threads(min(64, ncpu))
+        OS.unet_forward(sd_unet, x, 801.0, text, None)              # warm the allocator / weight pages once, untimed
     best, tried = None, {}
-    for nt in sorted({min(64, ncpu), min(128, ncpu), ncpu}):
+    for nt in sorted({min(64, ncpu), min(128, ncpu), ncpu}):        # ascending; stop as soon as more threads are slower (256 threads: 70x slower)
         torch.set_num_threads(nt)
         with torch.no_grad():
-            OS.unet_forward(sd_unet, x, 801.0, text, None)
             t0 = time.perf_counter()
             OS.unet_forward(sd_unet, x, 801.0, text, None)
         tried[nt] = time.perf_counter() - t0
         if best is None or tried[nt] < tried[best]:
             best = nt
+        else:
+            break
     torch.set_num_threads(best)
     return best, tried
 

@@ -66,7 +66,12 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
                           size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim,
                           float lambda_flow, float lambda_tv, float* feat, float* g, float* m, float* v, float* losses,
-                          float* images_out, void* ws, hipStream_t st);
+                          float* images_out, void* ws, void* lazy_ws, hipStream_t st);
+/* lazy_ws (may be NULL): tcl_stage2_lazy_workspace_bytes(K, iters) bytes.  With it (and ids_unique) the dense Adam of generate.py:483-487 is
+ * applied LAZILY: a codebook row is only read / written in the iterations whose mini-batch holds it, the steps it skipped in between (pure
+ * momentum decay, no gradient) are replayed with the same arithmetic right before it is needed, and one dense pass ends the stage -- the
+ * result is bit-identical to stepping all K rows every iteration, at ~(rows of the mini-batch) / K of the optimiser's HBM traffic. */
+size_t tcl_stage2_lazy_workspace_bytes(size_t K, int iters);
 
 /* One mini-batch of stage 1 / stage 2, GRADIENT ONLY (forward + backward of generate.py:396-429 / :496-522, no optimiser step): what the
  * whole-stage drivers above run per iteration, exposed so that a multi-GPU host loop can put a collective between the gradient and the

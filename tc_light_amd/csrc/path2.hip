@@ -14,6 +14,7 @@
 #include "../../include/tclight_hip.h"
 #include <math.h>
 #include <string.h>
+#include <vector>
 
 #define SH_C0 0.28209479177387814f
 #define ACC_SLOTS 32   // loss accumulators: [ACC_SLOTS][4] fixed-point cells = {l1, tv_h, tv_w, flow}
@@ -449,13 +450,92 @@ __global__ void k_loss_finalize(fx_t* acc, const float* ms_term, float w_photo, 
 }
 
 // ---------------------------------------------------------------- optimiser / init
-// torch.optim.Adam step; g is zeroed for the next iteration's atomics (saves a memset pass).
+// torch.optim.Adam, one element.  ONE function for the dense step, the lazy step and the replay of skipped steps (g = 0): the same
+// instruction sequence, so the lazy schedule below reproduces the dense one bit for bit.
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    // no fma contraction in here: the compiler is otherwise free to fuse b1*m + (1-b1)*g one way in one kernel and the other way in another (or
+    // to fold the g = 0 replay differently) -- a 1-ulp difference that Adam(eps 1e-15) turns into a +-lr step wherever momentum and gradient
+    // nearly cancel (measured: dense vs lazy 1 ulp apart after 2 iterations, 5e-3 after 25).  (HIP's __fmul_rn & co are plain operators.)
+#pragma clang fp contract(off)
+    const float mi = b1 * m + (1.f - b1) * g, vi = b2 * v + (1.f - b2) * g * g;
+    m = mi; v = vi;
+    p -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+// dense step; g is zeroed for the next iteration (saves a memset pass).
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
                        float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float gi = g[i], mi = b1 * m[i] + (1.f - b1) * gi, vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi; g[i] = 0.f;
-        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, mi, vi, g[i], lr, b1, b2, eps, bc1, bc2_sqrt);
+        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = 0.f;
+    }
+}
+// ---- LAZY dense Adam (stage 2, round 3).  The reference's Adam is dense: every codebook row moves every iteration through its momentum,
+// 84 B per row and iteration (p, g, m, v read; p, m, v written) -- at K ~ N H W rows (short tracks) that stream is 9/10 of the stage's
+// traffic, although only the rows of the mini-batch's 2 b frames receive a gradient.  A row's update in an iteration WITHOUT gradient is a
+// pure function of its own (p, m, v) and the step number, so it can be applied later: t_last[row] = the last step applied; before a row is
+// gathered (it is in the mini-batch) the steps t_last+1 .. it are replayed with g = 0 by the SAME instruction sequence the dense kernel runs
+// (adam_elem), then the step with its gradient follows, and one dense catch-up pass ends the stage.  Bit-identical to the dense schedule
+// (tests/test_gpu_path2.py::test_stage2_lazy_adam_equals_dense); traffic per iteration ~ the mini-batch's rows instead of all K.
+// Rows are visited frame by frame (one launch per cat row, like k_codebook_bwd<false>): ids are distinct inside a frame, and a row shared by
+// two frames of the batch is handled by whichever launch comes first (the t_last test).
+__device__ __forceinline__ void adam_replay(float (&p)[3], float (&m)[3], float (&v)[3], int from, int to, float lr, float b1, float b2, float eps,
+                                            const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    if (m[0] == 0.f && m[1] == 0.f && m[2] == 0.f && v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) return;      // never touched: every skipped step is a no-op
+    for (int s = from; s <= to; ++s) {
+        const float c1 = bc1[s], c2 = bc2[s];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) adam_elem(p[c], m[c], v[c], 0.f, lr, b1, b2, eps, c1, c2);
+    }
+}
+// rows of cat row j: bring them to step `upto` (no gradient)
+__global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int j, int P, size_t K, int* __restrict__ t_last,
+                                     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto, float lr, float b1, float b2,
+                                     float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    const int* iv = inv + (size_t)fidx[j] * P;
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
+        const size_t id = (size_t)iv[px];
+        const int tl = t_last[id];
+        if (tl >= upto) continue;
+        float pp[3], mm[3], vv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
+        adam_replay(pp, mm, vv, tl + 1, upto, lr, b1, b2, eps, bc1, bc2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c * K + id] = pp[c]; m[c * K + id] = mm[c]; v[c * K + id] = vv[c]; }
+        t_last[id] = upto;
+    }
+}
+// rows of cat row j that stand at step - 1: apply `step` with their gradient, clear it
+__global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int j, int P, size_t K, int* __restrict__ t_last,
+                                     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
+                                     float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    const int* iv = inv + (size_t)fidx[j] * P;
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
+        const size_t id = (size_t)iv[px];
+        if (t_last[id] != step - 1) continue;            // already stepped by an earlier frame of this mini-batch
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float pi = p[c * K + id], mi = m[c * K + id], vi = v[c * K + id];
+            adam_elem(pi, mi, vi, g[c * K + id], lr, b1, b2, eps, bc1, bc2_sqrt);
+            p[c * K + id] = pi; m[c * K + id] = mi; v[c * K + id] = vi; g[c * K + id] = 0.f;
+        }
+        t_last[id] = step;
+    }
+}
+// end of the stage: every row to the last step
+__global__ void k_adam_catchup_all(size_t K, int* __restrict__ t_last, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto,
+                                   float lr, float b1, float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < K; id += (size_t)gridDim.x * blockDim.x) {
+        const int tl = t_last[id];
+        if (tl >= upto) continue;
+        float pp[3], mm[3], vv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
+        adam_replay(pp, mm, vv, tl + 1, upto, lr, b1, b2, eps, bc1, bc2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c * K + id] = pp[c]; m[c * K + id] = mm[c]; v[c * K + id] = vv[c]; }
+        t_last[id] = upto;
     }
 }
 template <bool ATOMIC>
@@ -616,6 +696,7 @@ static StageWs carve_stage(char* base, int b, int h, int w) {
     return S;
 }
 size_t tcl_stage_workspace_bytes(int batch, int h, int w) { return carve_stage(nullptr, batch, h, w).bytes + 256; }
+size_t tcl_stage2_lazy_workspace_bytes(size_t K, int iters) { return ((K * 4 + 255) & ~(size_t)255) + (size_t)2 * (iters + 1) * 4 + 256; }
 
 static double expon_lr(int step, double lr_init, double lr_final, int max_steps) {  // general_utils.py:31-64, delay off
     double t = (double)step / max_steps; t = t < 0 ? 0 : (t > 1 ? 1 : t);
@@ -717,22 +798,47 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
 int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
                           size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
                           float lambda_tv, float* feat, float* g, float* m, float* v, float* losses, float* images_out, void* ws,
-                          hipStream_t st) {
+                          void* lazy_ws, hipStream_t st) {
     TCL_CHECK_ARG(target && flows && masks && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
     TCL_CHECK_ARG(N > 0 && batch > 0 && batch <= 64 && iters >= 0 && H > 160 && W > 160 && K > 0);
     const size_t P = (size_t)H * W;
     const float lr = feature_lr * (float)batch / (float)N;
+    // lazy dense Adam (see k_adam_catchup_frame): needs the frame-ordered row visits (ids_unique) and the caller's t_last / table scratch
+    const bool lazy = lazy_ws && ids_unique && iters > 0;
+    int* t_last = nullptr; float *bc1 = nullptr, *bc2 = nullptr;
+    if (lazy) {
+        t_last = (int*)lazy_ws;
+        bc1 = (float*)((char*)lazy_ws + ((K * 4 + 255) & ~(size_t)255)); bc2 = bc1 + (iters + 1);
+        static std::vector<float> tab;                                       // bias corrections of steps 1 .. iters, as tcl_adam_step computes them
+        tab.assign(2 * (size_t)(iters + 1), 1.f);
+        for (int sidx = 1; sidx <= iters; ++sidx) { tab[sidx] = (float)(1.0 - pow((double)0.9f, sidx)); tab[iters + 1 + sidx] = (float)sqrt(1.0 - pow((double)0.999f, sidx)); }   // (double)b1 of the FLOAT b1, like tcl_adam_step
+        if (hipMemsetAsync(t_last, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        if (hipMemcpyAsync(bc1, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) return TCL_ELAUNCH;
+    }
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
-        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, ids_unique, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim,
+        const int* cidx = d_cat + (size_t)it * 2 * batch;
+        if (lazy)       // the mini-batch's rows catch up with the steps they skipped (1 .. it), frame by frame, before they are gathered
+            for (int j = 0; j < 2 * b; ++j)
+                hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 1), dim3(256), 0, st, unq_inv, cidx, j, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,
+                                   1e-15f, bc1, bc2);
+        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
                                         lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
         if (rc) return rc;
-        rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
-        if (rc) return rc;
+        if (lazy) {
+            const float c1 = (float)(1.0 - pow((double)0.9f, it + 1)), c2 = (float)sqrt(1.0 - pow((double)0.999f, it + 1));
+            for (int j = 0; j < 2 * b; ++j)
+                hipLaunchKernelGGL(k_adam_touched_frame, pgrid(P, 1), dim3(256), 0, st, unq_inv, cidx, j, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
+                                   0.999f, 1e-15f, c1, c2);
+        } else {
+            rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
+            if (rc) return rc;
+        }
     }
+    if (lazy) hipLaunchKernelGGL(k_adam_catchup_all, dim3(stream_grid((long)K, 256, 1)), dim3(256), 0, st, K, t_last, feat, m, v, iters, lr, 0.9f, 0.999f, 1e-15f, bc1, bc2);
     if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P, K);
     TCL_LAUNCH_RET();
 }

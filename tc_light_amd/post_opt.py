@@ -8,6 +8,8 @@ Same names / argument meaning as the reference (SURVEY 8(b) "Stage-1/2 ops"):
   exposure_align / unique_tensor_optimization      generate.py:354 / :453
 The three loss ops are torch.autograd.Functions whose forward AND backward are HIP kernels.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -236,9 +238,13 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
         g, m, v = (torch.zeros_like(feat) for _ in range(3))
         losses = torch.zeros(max(len(sched), 1), device=dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
+        # lazy dense Adam (csrc/path2.hip): pays when the codebook is much larger than the rows one mini-batch touches (2 b frames)
+        lazy = os.environ.get("TCL_ADAM_LAZY", "auto")
+        use_lazy = uniq and len(sched) > 0 and (lazy == "1" or (lazy == "auto" and k > 3 * 2 * batch_size * h * w))
+        lws = torch.empty(L.tcl_stage2_lazy_workspace_bytes(k, len(sched)), dtype=torch.uint8, device=dev) if use_lazy else 0
         L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, uniq, sched.ctypes.data, d_cat,
                                 len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
-                                losses, out, ws, stream())
+                                losses, out, ws, lws, stream())
         losses = losses[:len(sched)]
     else:
         from .parallel import distributed_adam_loop

@@ -139,6 +139,26 @@ def test_stage1_stage2_bit_reproducible(ops):
     assert torch.isfinite(out_d).all() and torch.isfinite(l2d).all()
 
 
+def test_stage2_lazy_adam_equals_dense(ops, monkeypatch):
+    """The reference's Adam over the codebook is dense (every row moves every iteration through its momentum).  The lazy schedule only visits
+    the rows of the mini-batch's frames and replays the gradient-free steps a row skipped right before it is needed; it must reproduce the dense
+    schedule BIT FOR BIT: codebook, relit frames and every loss, on a clip whose tracks are short (K >> rows of a mini-batch) and long."""
+    for reuse in (0.15, 0.8):
+        d = synth.video_clip(10, 200, 224, seed=23, shift=(1.4, 0.3))
+        inv, k = synth.track_ids(10, 200, 224, seed=6, reuse=reuse)
+        bts = synth.batches(10, 2, epochs=5, seed=9)                 # 25 iterations: most rows sit out many steps between two visits
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("TCL_ADAM_LAZY", mode)
+            ds = ops.OptDataset(d["edited"], d["past_flows"], d["masks"], device="cuda")
+            out, feat, l2 = ops.unique_tensor_optimization(ds, inv.cuda(), bts, batch_size=2, k=k)
+            torch.cuda.synchronize()
+            res[mode] = (out.clone(), feat.contiguous().clone(), l2.clone())
+        for a_, b_, name in zip(res["0"], res["1"], ("relit frames", "codebook", "losses")):
+            assert torch.equal(a_, b_), (reuse, name, (a_ - b_).abs().max().item())
+        assert float(res["0"][2][0]) != float(res["0"][2][-1])                   # (the optimiser did move)
+
+
 def test_full_size_properties(ops):
     """Config-(2)-sized checks through size-independent properties (the oracle would take minutes here)."""
     h, w = 720, 960

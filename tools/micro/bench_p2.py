@@ -1,9 +1,10 @@
 """Stage 1 / stage 2 of path 2 alone, whole-stage drivers, at a BASELINE size: ms per iteration and the algorithmic HBM rate (SURVEY 8(d):
-stage 2 = (56 + 48 + 24) b P + 84 K bytes per iteration, stage 1 = 2 x 60 b P).  usage: bench_p2.py [frames H W iters]   (default: config 2)"""
+stage 2 = (56 + 48 + 24) b P + 84 K bytes per iteration, stage 1 = 2 x 60 b P).  usage: bench_p2.py [frames H W iters [reuse]]   (default: config 2)"""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch, time
 from tc_light_amd import post_opt as P
 n, h, w, iters = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (30, 720, 960, 20)))
+reuse = float(sys.argv[5]) if len(sys.argv) > 5 else 0.7      # fraction of a frame's pixels that continue a track (0.02: K ~ N H W, the bench clip's regime)
 g = torch.Generator(device="cuda").manual_seed(1)
 base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, h + 8, w + n + 8, device="cuda", generator=g), 9, stride=1, padding=4)
 ed = torch.stack([base[0, :, 4:4 + h, i:i + w] for i in range(n)]).contiguous()
@@ -15,7 +16,7 @@ flows = flows * (1 + 0.1 * torch.randn(n, 1, 1, 1, device="cuda", generator=g)) 
 masks = (torch.rand(n, 1, h, w, device="cuda", generator=g) > 0.1).float()
 ids = torch.empty(n, h, w, dtype=torch.int64, device="cuda"); ids[0] = torch.arange(h * w, device="cuda").view(h, w); last = h * w
 for k in range(1, n):
-    fresh = torch.rand(h, w, device="cuda", generator=g) > 0.7; fresh[:, 0] = True
+    fresh = torch.rand(h, w, device="cuda", generator=g) > reuse; fresh[:, 0] = True
     cur = torch.roll(ids[k - 1], 1, dims=1); c = int(fresh.sum()); cur[fresh] = last + torch.arange(c, device="cuda"); last += c; ids[k] = cur
 inv, K = ids.reshape(-1).to(torch.int32), last
 rng = np.random.default_rng(0)

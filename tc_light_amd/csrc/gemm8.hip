@@ -527,21 +527,31 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
         wdst[i] = real ? q * 1024 : -1;
     }
     const int nk = K / KB;
-    // piece I of stage KT (KT >= nk: a dummy that re-reads the last stage into the dump area, so that every wave issues NP pieces per stage)
-#define G8P_FIRE(KT, I)                                                                                                       \
+    // Scalars of the stage being issued, computed ONCE per (half) step by G8P_STAGE and shared by its NP pieces: ring slot, K offsets of the two
+    // operands (conv: tap + channel slice -> input offset and weight column), whether the stage exists at all (stages past the end are issued
+    // as dummies that re-read the last stage into the dump area, so that every wave issues NP pieces per stage and the vmcnt counts are
+    // constants).  The first version recomputed all of it inside every piece, pinned between two MFMAs: 6.7 scalar instructions per MFMA
+    // (rocprofv3 SQ_INSTS_SALU, profiles/r3_gemm8p_counters_*.txt).
+    char* st_base = smem; unsigned st_ka = 0, st_kw = 0; int st_tap = 0; bool st_ex = false;
+#define G8P_STAGE(KT)                                                                                                         \
     {                                                                                                                         \
         const int kt_ = min((KT), nk - 1);                                                                                    \
-        char* sb_ = smem + ((KT) % NS) * STAGE;                                                                               \
+        st_ex = (KT) < nk; st_base = smem + ((KT) % NS) * STAGE;                                                              \
+        int ka_ = kt_ * KB, kw_ = ka_; st_tap = 0;                                                                            \
+        if (CONV) { int c0_; st_tap = conv_kmap(ka_, cp.Cin, c0_); kw_ = st_tap * cp.Cin + c0_; ka_ = ((st_tap / 3) * cp.Win + st_tap % 3) * cp.Cin + c0_; } \
+        st_ka = (unsigned)ka_ * 2u; st_kw = (unsigned)kw_ * 2u;                                                               \
+    }
+    // piece I of the stage G8P_STAGE prepared
+#define G8P_FIRE(I)                                                                                                           \
+    {                                                                                                                         \
         char* dump_ = smem + NS * STAGE;                                                                                      \
-        int ka_ = kt_ * KB, kw_ = ka_, tap_ = 0;                                                                              \
-        if (CONV) { int c0_; tap_ = conv_kmap(ka_, cp.Cin, c0_); kw_ = tap_ * cp.Cin + c0_; ka_ = ((tap_ / 3) * cp.Win + tap_ % 3) * cp.Cin + c0_; } \
         if ((I) < NPA) {                                                                                                      \
-            unsigned vo_ = aoff[(I) < NPA ? (I) : 0] + (unsigned)ka_ * 2u;                                                    \
-            if (CONV) vo_ = ((amask[(I) < NPA ? (I) : 0] >> tap_) & 1u) ? vo_ : 0xffffffffu;                                  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)((KT) < nk ? sb_ + (wid + 8 * (I)) * 1024 : dump_), 16, vo_, 0, 0, 0); \
+            unsigned vo_ = aoff[(I) < NPA ? (I) : 0] + st_ka;                                                                 \
+            if (CONV) vo_ = ((amask[(I) < NPA ? (I) : 0] >> st_tap) & 1u) ? vo_ : 0xffffffffu;                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(st_ex ? st_base + (wid + 8 * (I)) * 1024 : dump_), 16, vo_, 0, 0, 0); \
         } else {                                                                                                              \
             const int iw_ = (I) >= NPA ? (I) - NPA : 0;                                                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(((KT) < nk && wdst[iw_] >= 0) ? sb_ + wdst[iw_] : dump_), 16, woff[iw_] + (unsigned)kw_ * 2u, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)((st_ex && wdst[iw_] >= 0) ? st_base + wdst[iw_] : dump_), 16, woff[iw_] + st_kw, 0, 0, 0); \
         }                                                                                                                     \
     }
 
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
             acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks_][a_], fb[ks_][b_], acc[a_][b_], 0, 0, 0);            \
             if (!(G8_ABL & 1) && ((mi + (FOFF)) % nM) % G == 0 && ((mi + (FOFF)) % nM) / G < NP) {                            \
                 __builtin_amdgcn_sched_barrier(0);                                                                            \
-                G8P_FIRE(KT, ((mi + (FOFF)) % nM) / G);                                                                       \
+                G8P_FIRE(((mi + (FOFF)) % nM) / G);                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                                            \
             }                                                                                                                 \
         }                                                                                                                     \
@@ -587,8 +597,9 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
     // prologue: stages 0 .. 2 whole; stages 0 and 1 landed before the first reads (B_0 certifies stage 1)
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
+        G8P_STAGE(s);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) G8P_FIRE(s, i);
+        for (int i = 0; i < NP; ++i) G8P_FIRE(i);
     }
     wait_vm<NP>();
     __builtin_amdgcn_s_barrier();
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
             __builtin_amdgcn_s_barrier();               // B_t
             G8P_T(0)
             G8P_READL(t, 1);
+            G8P_STAGE(t + PD);
             G8P_MRANGE(t + PD, 0, HALF, 0);
             G8P_T(1)
             G8P_READL(t + 1, 0);
@@ -612,13 +624,15 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     } else {
+        G8P_STAGE(PD);
 #pragma unroll
         for (int q = 0; q < NP; ++q)
-            if (q * G < HALF) G8P_FIRE(PD, q);          // the "half step -1" part of stage 3
+            if (q * G < HALF) G8P_FIRE(q);              // the "half step -1" part of stage 3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // B_0
         for (int t = 0; t < nk; ++t) {
             G8P_READL(t, 1);
+            G8P_STAGE(t + PD);
             G8P_MRANGE(t + PD, 0, HALF, HALF);          // second part of stage t+3
             G8P_T(1)
             wait_vm<NP>();
@@ -627,6 +641,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
             __builtin_amdgcn_s_barrier();               // B_t+1
             G8P_T(0)
             G8P_READL(t + 1, 0);
+            G8P_STAGE(t + 1 + PD);
             G8P_MRANGE(t + 1 + PD, HALF, nM, HALF);     // first part of stage t+4
             G8P_T(3)
         }
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(512) void k_gemm8p(const _Float16* __restrict__ A, 
     wait_vm<0>();                                       // dummy pieces (dump area) and group 1's early part of a stage past the end
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last half step's look-ahead reads (unused) before the epilogue rewrites the LDS
 #undef G8P_FIRE
+#undef G8P_STAGE
 #undef G8P_READK
 #undef G8P_READL
 #undef G8P_MRANGE

@@ -48,7 +48,7 @@ __global__ void k_diff(const unsigned* a, const unsigned* b, size_t n, unsigned*
     if (c) atomicAdd(cnt, c);
 }
 
-struct Shape { int conv, M, N, K, B, H, W, Cin, up; const char* name; };
+struct Shape { int conv, M, N, K, B, H, W, Cin, up; const char* name; int stride = 1, pad = 1; };
 
 int main(int argc, char** argv) {
     std::vector<Shape> shapes = {
@@ -80,6 +80,9 @@ int main(int argc, char** argv) {
         {1, 0, 640, 0, 64, 45, 80, 1280, 0, "conv 1280->640 @45x80 x64"},
         {1, 0, 1280, 0, 64, 23, 40, 1280, 0, "conv 1280->1280 @23x40 x64"},
         {1, 0, 1280, 0, 64, 23, 40, 2560, 0, "conv 2560->1280 @23x40 x64"},
+        // stride 2 (UNet down-samplers; the VAE encoder's pad-0 variant with its asymmetric (0,1,0,1) padding): the tap masks of k_gemm8p
+        {1, 0, 320, 0, 64, 90, 160, 320, 0, "conv 320->320 stride 2 @90x160 x64", 2, 1},
+        {1, 0, 256, 0, 16, 180, 320, 256, 0, "conv 256->256 stride 2 pad 0 @180x320 x16 (VAE encoder)", 2, 0},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const unsigned smask = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0x7u;      // bit s = time schedule s
@@ -95,7 +98,9 @@ int main(int argc, char** argv) {
         size_t a_elems;
         if (s.conv) {
             cp.conv = 1; cp.Hin = s.H; cp.Win = s.W; cp.Cin = s.Cin; cp.Hup = s.up ? 2 * s.H : s.H; cp.Wup = s.up ? 2 * s.W : s.W;
-            cp.stride = 1; cp.pad = 1; cp.Hout = cp.Hup; cp.Wout = cp.Wup; cp.sy = (float)cp.Hin / cp.Hup; cp.sx = (float)cp.Win / cp.Wup;
+            cp.stride = s.stride; cp.pad = s.pad; cp.sy = (float)cp.Hin / cp.Hup; cp.sx = (float)cp.Win / cp.Wup;
+            cp.Hout = s.pad ? (cp.Hup + 2 - 3) / s.stride + 1 : (cp.Hup + 1 - 3) / s.stride + 1;
+            cp.Wout = s.pad ? (cp.Wup + 2 - 3) / s.stride + 1 : (cp.Wup + 1 - 3) / s.stride + 1;
             M = s.B * cp.Hout * cp.Wout; K = 9 * s.Cin; a_elems = (size_t)s.B * s.H * s.W * s.Cin;
         } else a_elems = (size_t)M * K;
         _Float16 *A, *Wt, *C0, *C1;

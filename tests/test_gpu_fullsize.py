@@ -183,7 +183,8 @@ def test_attention_trained_like_logits(L):
     kk, vv = (t.float().view(B, Tq, Hh, d).transpose(1, 2) for t in (k, v))
     ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, -1, C)
     assert torch.isfinite(o).all()
-    per_head = ((o[:, rows].float() - ref).view(B, -1, Hh, d).norm(dim=(0, 1, 3)) / ref.view(B, -1, Hh, d).norm(dim=(0, 1, 3))).cpu()
+    l2 = lambda t: t.view(B, -1, Hh, d).pow(2).sum(dim=(0, 1, 3)).sqrt()
+    per_head = (l2(o[:, rows].float() - ref) / l2(ref)).cpu()
     print("[attention, trained-like logits] rel-L2 per head:", [f"{x:.1e}" for x in per_head.tolist()])
     assert rel(o[:, rows], ref) < 7e-4 and per_head.max() < 1.5e-3
 

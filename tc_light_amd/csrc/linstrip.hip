@@ -1,0 +1,197 @@
+// Short-K Linear layers (K = 320: q / k / v / out projections, proj_in / proj_out, the GEGLU feed-forward of the level-0 transformer
+// blocks: generate.py:342-347 -> diffusers BasicTransformerBlock), strip-resident form.
+// A tiled GEMM spends a K = 320 problem in its prologue and epilogue (ten 32-wide K steps per tile: matrix pipe 25 % busy, 1.5-2.4 TB/s,
+// profiles/r3_gemm_dma_counters.txt).  Here the decomposition is the one of the VidToMe matching kernel (merge.hip::k_tome_match320,
+// matrix pipe 54 %): a block OWNS a strip of 128 activation rows -- each wave keeps the MFMA B operand of its 32 rows in registers for
+// ALL of K (20 half8 = 80 VGPRs), read from HBM exactly once -- and SWEEPS the weight rows in tiles of 128, which stream from L2
+// through a 4-slot LDS ring by LDS-DMA (64-wide K stages, 128 B per row, 16-B chunks XOR-swizzled).  The sweep is one long pipeline
+// (N = 2560: 100 stages), the epilogue of a tile overlaps the next tile's DMA, and C leaves in 16-B pieces straight from registers:
+// the two lanes that share an output row exchange half of their packed results with v_permlane32_swap, no LDS staging.
+// Results are bit-identical to every other tile configuration of csrc/gemm.hip: same MFMA (32x32x16 f16), same K order, same
+// epilogue arithmetic (f16(act(acc + bias)), then f16(post_act(. + resid)); GEGLU on the [32 value | 32 gate] row groups of unet.py::_geglu_rows).
+#include "common.h"
+#include "gemm_conv.h"
+#include <stdlib.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+// 16 results of a lane (one 32 x 32 MFMA tile: row n = 8 (r >> 2) + 4 hl + (r & 3), column = the lane's activation row) -> the two 16-B
+// pieces the lane stores: columns [8 hl, 8 hl + 8) and [16 + 8 hl, 16 + 8 hl + 8) of the tile's 32 output columns.
+__device__ __forceinline__ void ls_exchange(const _Float16 (&o)[16], uint4v& p0, uint4v& p1) {
+    unsigned d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { half2v h = {o[2 * q], o[2 * q + 1]}; d[q] = __builtin_bit_cast(unsigned, h); }
+    // lane L < 32 keeps (d0, d1) and takes the partner's (d0, d1); lane L + 32 takes L's (d2, d3) and keeps its own
+    const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(d[4], d[6], false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(d[5], d[7], false, false);
+    p0 = uint4v{s0[0], s1[0], s0[1], s1[1]};
+    p1 = uint4v{s2[0], s3[0], s2[1], s3[1]};
+}
+
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                                       const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
+                                                                       _Float16* __restrict__ C, int M, int N, int lda, int ldw, int ldc, int ldr,
+                                                                       int act, int tiles_n, int nsplit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NST = K / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
+    _Float16* const sbias = (_Float16*)(smem + 4 * STAGE);                       // the block's bias range, 128 entries per tile
+    const int bid = blockIdx.x, split = bid % nsplit, strip = bid / nsplit;     // the splits of a strip are neighbours: its rows are fetched once into L2
+    const int tps = (tiles_n + nsplit - 1) / nsplit, t0 = split * tps, t1 = min(t0 + tps, tiles_n);
+    if (t0 >= t1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, col = lane & 31;
+    const int ntl = t1 - t0, nstep = ntl * NST;
+    // DMA roles (as k_tome_match320): wave w stages pieces NP w .. NP w + NP - 1 of a stage (8 weight rows x 128 B each); a piece's source is a
+    // scalar base plus one of two per-lane byte offsets (the swizzle term of row R = 8 piece + rr only depends on the piece's parity)
+    const int rr = lane >> 3, ch = lane & 7;
+    const int voff0 = rr * (ldw * 2) + ((ch ^ (rr >> 1)) << 4), voff1 = rr * (ldw * 2) + ((ch ^ (4 + (rr >> 1))) << 4);
+    const int m = strip * SW + wid * 32 + col;                                   // this lane's activation row = output row
+    const bool live = m < M;
+    half8 bfr[K / 16];                                                            // B operand: row m, k = 16 ks + 8 hl .. + 7
+    {
+        const _Float16* ap = A + (long)(live ? m : 0) * lda + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) bfr[ks] = *(const half8*)(ap + ks * 16);
+    }
+    for (int i = tid; i < ntl * 128; i += 64 * NW) {                              // bias of the swept tiles (the last tile is moved back, like its rows)
+        const int n = min((t0 + i / 128) * 128, N - 128) + (i & 127);
+        sbias[i] = bias ? bias[n] : (_Float16)0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  // the only non-DMA VMEM reads before the loop; bias in LDS before the first barrier
+    int i_t = 0, i_k = 0;                                                         // (tile, stage) of the step being ISSUED
+#define LS_ISSUE(BUF)                                                                                                         \
+    {                                                                                                                         \
+        const int n0_ = min((t0 + i_t) * 128, N - 128);                                                                       \
+        const char* sb_ = (const char*)W + ((long)(n0_ + wid * (8 * NP)) * ldw + i_k * 64) * 2;                               \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                     \
+            const char* src_ = sb_ + (long)i * (8 * ldw * 2) + ((i & 1) ? voff1 : voff0);                                     \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
+                                             (__attribute__((address_space(3))) void*)(lds0 + (BUF) * STAGE + (wid * NP + i) * 1024), 16, 0, 0); \
+        }                                                                                                                     \
+        if (++i_k == NST) { i_k = 0; ++i_t; }                                                                                 \
+    }
+    LS_ISSUE(0);
+    if (nstep > 1) LS_ISSUE(1);
+    int step = 0;
+    for (int tl = 0; tl < ntl; ++tl) {
+        float16v acc[4];
+#pragma unroll
+        for (int kt = 0; kt < NST; ++kt, ++step) {
+            // 4-slot ring, two K stages per barrier: steps s, s+1 (s even) are consumed while s+2, s+3 stream into the slots of s-2, s-1.
+            // The epilogue's stores and residual loads are VMEM too: vmcnt(0) at the barrier drains them with the DMA (in order anyway).
+            if ((step & 1) == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (step + 2 < nstep) LS_ISSUE((step + 2) & 3);
+                if (step + 3 < nstep) LS_ISSUE((step + 3) & 3);
+            }
+            const char* db = smem + (step & 3) * STAGE;
+            half8 fa[2][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[0][a] = *(const half8*)(db + R * 128 + (((0 + hl) ^ ((R >> 1) & 7)) << 4)); }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[(ks + 1) & 1][a] = *(const half8*)(db + R * 128 + (((2 * (ks + 1) + hl) ^ ((R >> 1) & 7)) << 4)); }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (kt == 0 && ks == 0) {
+                        float16v z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][a], bfr[0], z, 0, 0, 0);
+                    } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue of the tile: 128 output columns [n0, n0 + 128) of the lane's row (64 with GEGLU)
+        const int n0 = min((t0 + tl) * 128, N - 128);
+        const _Float16* bt = sbias + tl * 128 + 4 * hl;
+        if (act == 2) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {                                      // rows [64 g2, +32) value, [64 g2 + 32, +32) the matching gates
+                _Float16 o[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const half4 bv = *(const half4*)(bt + g2 * 64 + 8 * q), bg = *(const half4*)(bt + g2 * 64 + 32 + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const _Float16 va = (_Float16)(acc[2 * g2][4 * q + j] + (float)bv[j]), vg = (_Float16)(acc[2 * g2 + 1][4 * q + j] + (float)bg[j]);
+                        o[4 * q + j] = (_Float16)((float)va * gelu_erf((float)vg));
+                    }
+                }
+                uint4v p0, p1;
+                ls_exchange(o, p0, p1);
+                if (live) {
+                    _Float16* cp = C + (long)m * ldc + (n0 >> 1) + g2 * 32 + 8 * hl;
+                    *(uint4v*)cp = p0;
+                    *(uint4v*)(cp + 16) = p1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                _Float16 o[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const half4 bv = *(const half4*)(bt + a * 32 + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[4 * q + j] = (_Float16)apply_act(acc[a][4 * q + j] + (float)bv[j], act);
+                }
+                uint4v p0, p1;
+                ls_exchange(o, p0, p1);
+                if (live) {
+                    const long off = n0 + a * 32 + 8 * hl;
+                    if (resid) {
+                        const half8 r0 = *(const half8*)(resid + (long)m * ldr + off), r1 = *(const half8*)(resid + (long)m * ldr + off + 16);
+                        half8 v0 = __builtin_bit_cast(half8, p0), v1 = __builtin_bit_cast(half8, p1);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            v0[j] = (_Float16)post_act((float)v0[j] + (float)r0[j], act);
+                            v1[j] = (_Float16)post_act((float)v1[j] + (float)r1[j], act);
+                        }
+                        p0 = __builtin_bit_cast(uint4v, v0); p1 = __builtin_bit_cast(uint4v, v1);
+                    }
+                    _Float16* cp = C + (long)m * ldc + off;
+                    *(uint4v*)cp = p0;
+                    *(uint4v*)(cp + 16) = p1;
+                }
+            }
+        }
+    }
+#undef LS_ISSUE
+#endif
+}
+
+// cfg 12 of csrc/gemm.hip.  Valid for dense A, K == 320, N >= 128 and N % 32 == 0 (GEGLU: N % 64 == 0), 16-B aligned rows.
+bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
+    return !cp.conv && K == 320 && N >= 128 && N % (act == 2 ? 64 : 32) == 0 && N <= 8192 && (lda & 7) == 0 && (ldw & 7) == 0 && (ldc & 7) == 0 &&
+           (!has_resid || (ldr & 7) == 0) && (long)ldw * 2 * 8 < (1l << 30);
+}
+
+int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
+                       int lda, int ldw, int ldc, int ldr, int act, hipStream_t st) {
+    if (K != 320) return TCL_EINVAL;
+    constexpr int NW = 4;
+    const int tn = cdiv(N, 128), strips = cdiv(M, 32 * NW);
+    // enough blocks for ~3 rounds of the 512 slots (2 per CU); a split re-reads the strip (from L2) and sweeps its share of the weight tiles
+    static const int force_split = getenv("TCL_LS_SPLIT") ? atoi(getenv("TCL_LS_SPLIT")) : 0;      // lab hook
+    int nsplit = 1;
+    while (nsplit < 8 && (long)strips * nsplit < 512 * 2 && tn / (nsplit * 2) >= 2) nsplit *= 2;
+    if (force_split > 0 && tn / force_split >= 1) nsplit = force_split;
+    const size_t lds = (size_t)4 * 128 * 128 + (size_t)cdiv(tn, nsplit) * 128 * 2;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_lin_strip<320, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128 + 64 * 128 * 2); set = true; }
+    hipLaunchKernelGGL((k_lin_strip<320, NW>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit);
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}

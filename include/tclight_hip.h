@@ -132,6 +132,9 @@ int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void
                       int groups, float eps, int silu, void* ws, hipStream_t st);
 /* torch.nn.LayerNorm(C) (BasicTransformerBlock.norm1/2/3). */
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st);
+/* The same, plus metric = y / |y| per row with tcl_tome_normalize_f16's f16 arithmetic (norm1 of a VidToMe-patched block, patch.py:161-166 ->
+ * merge.py:84: the matching metric of the block's tokens, produced while they are in registers). */
+int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st);
 /* diffusers GEGLU: in [rows, 2D] -> out [rows, D] = in[:, :D] * gelu(in[:, D:]) (exact erf gelu). */
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st);
 /* in-place softmax(scale * x) over rows of length T (VAE mid-block single-head attention). */

@@ -112,8 +112,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+// METRIC: also write the row's cosine-normalised form y / |y| for the VidToMe matching of this block (merge.py:84: metric / metric.norm()),
+// with exactly the arithmetic and summation order of merge.hip::k_tome_normalize on the f16 y -- same lane <-> chunk layout -- so the
+// matching sees the same bits as when it normalised the tokens itself (one launch and one read of the tokens less per chunk and block).
+template <bool METRIC>
 __global__ __launch_bounds__(256) void k_layernorm(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
-                                                   const _Float16* __restrict__ beta, _Float16* __restrict__ y, long rows, int C, float eps) {
+                                                   const _Float16* __restrict__ beta, _Float16* __restrict__ y, _Float16* __restrict__ metric,
+                                                   long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const _Float16* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { float d = (float)v[k][j] - mean; q += d * d; }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float q2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int ch = lane + 64 * k;
@@ -142,7 +148,21 @@ __global__ __launch_bounds__(256) void k_layernorm(const _Float16* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[k][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
             *(h8*)(y + row * C + ch * 8) = o;
+            if (METRIC) {
+                v[k] = o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q2 += (float)o[j] * (float)o[j];
+            }
         }
+    }
+    if (METRIC) {
+        const float nrm = (float)(_Float16)sqrtf(wave_sum(q2));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < nchunk) { h8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[k][j] / nrm);
+                *(h8*)(metric + row * C + (lane + 64 * k) * 8) = o; }
     }
 }
 
@@ -390,8 +410,14 @@ int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void
 }
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st) {
     TCL_CHECK_ARG(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048);
-    hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
-                       (_Float16*)y, rows, C, eps);
+    hipLaunchKernelGGL(k_layernorm<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
+                       (_Float16*)y, (_Float16*)nullptr, rows, C, eps);
+    TCL_LAUNCH_RET();
+}
+int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st) {
+    TCL_CHECK_ARG(x && gamma && beta && y && metric && rows > 0 && C % 8 == 0 && C <= 2048);
+    hipLaunchKernelGGL(k_layernorm<true>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
+                       (_Float16*)y, (_Float16*)metric, rows, C, eps);
     TCL_LAUNCH_RET();
 }
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st) {

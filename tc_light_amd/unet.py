@@ -101,8 +101,12 @@ class Ops:
         self.L.tcl_groupnorm_f16(x1, c1, x2 if x2 is not None else 0, c2, gamma, beta, y, B, HW, groups, eps, int(silu), ws, stream())
         return y
 
-    def layernorm(self, x, gamma, beta, rows, C):
+    def layernorm(self, x, gamma, beta, rows, C, metric=False):
         y = self.empty(rows, C)
+        if metric:          # norm1 of a VidToMe-patched block: the matching metric y / |y| leaves the same kernel
+            m = self.empty(rows, C)
+            self.L.tcl_layernorm_metric_f16(x, gamma, beta, y, m, rows, C, 1e-5, stream())
+            return y, m
         self.L.tcl_layernorm_f16(x, gamma, beta, y, rows, C, 1e-5, stream())
         return y
 
@@ -239,7 +243,19 @@ class UNetEngine:
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            prio = os.environ.get("TCL_SIDE_PRIO", "")
+            if prio == "low":       # experiment: lowest HIP stream priority for the matching chain (torch only hands out default / high ones)
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+                hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
+                h = ctypes.c_void_p()
+                rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 0, lo.value)
+                assert rc == 0, rc
+                print(f"[unet] side stream priority {lo.value} (range least {lo.value} .. greatest {hi.value})", flush=True)
+                self._side = torch.cuda.ExternalStream(h.value, device=self.dev)
+            else:
+                self._side = torch.cuda.Stream(device=self.dev, priority=-1 if prio == "high" else 0)
         return self._side
 
     def _transformer(self, p, x, B, Fs, Hh, Ww, text):
@@ -255,7 +271,8 @@ class UNetEngine:
         h = o.gemm(hn, blk["pin"][0], blk["pin"][1])
         self._fl(2.0 * M * C * C * 2)
         # ---- attn1 over VidToMe-merged tokens (patch.py:161-179)
-        n1 = o.layernorm(h, *blk["ln"][0], M, C)
+        merging = self.tome.merges(N) and os.environ.get("TCL_LN_METRIC", "1") != "0"
+        n1, m1 = o.layernorm(h, *blk["ln"][0], M, C, metric=True) if merging else (o.layernorm(h, *blk["ln"][0], M, C), None)
         if not self.tome.merges(N):                             # downsample > max_downsample: per-frame attention
             qkv = o.gemm(n1, blk["qkv"])
             a = o.attention(qkv, 3 * C, N * 3 * C, qkv[:, C:], 3 * C, N * 3 * C, qkv[:, 2 * C:], 3 * C, N * 3 * C, B, Hd, N, N, d)
@@ -275,7 +292,8 @@ class UNetEngine:
             for ci, F in enumerate(Fs):
                 self.tome.select_chunk(ci)
                 with torch.cuda.stream(side):
-                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs)     # merged [2, T, C]
+                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
+                                                             metric=m1[off * N:] if m1 is not None else None)     # merged [2, T, C]
                 if two:
                     ev = torch.cuda.Event()
                     ev.record(side)

@@ -135,20 +135,25 @@ class VidToMe:
             for b in range(2):
                 L.tcl_gather_add_rows_f16(fh[b * bsh:], bsh, fy[b * T * C:], T * C, unm[b], 1, n, C, stream())
 
-    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None):
+    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None, metric=None):
         """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps ([2, .]
-        each without align_batch).
+        each without align_batch).  metric: the tokens' cosine-normalised rows in the same layout, when the producer already wrote them
+        (tcl_layernorm_metric_f16); otherwise they are normalised here.
         affine = (a_split, a_gap, b0): a_pos[i] = i if i < a_split else i + a_gap, b_pos[j] = b0 + j (true of the single-round VidToMe matches;
         lets the C = 320 matches take the strip-resident kernel, csrc/merge.hip::k_tome_match320 -- same maps, bit for bit)."""
         L = self.L
         r = min(na, int(na * ratio))                                            # merge.py:90
-        metric = torch.empty(2 * T, C, dtype=H16, device=self.dev)
-        if tbs is None or tbs == T * C:
-            L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+        mbs = T * C                                                             # elements between the two batch entries of the metric
+        if metric is not None:
+            metric, mbs = metric.reshape(-1), (T * C if tbs is None else tbs)
         else:
-            flat = tokens.reshape(-1)
-            L.tcl_tome_normalize_f16(flat, metric, T, C, stream())
-            L.tcl_tome_normalize_f16(flat[tbs:], metric[T:], T, C, stream())
+            metric = torch.empty(2 * T * C, dtype=H16, device=self.dev)
+            if tbs is None or tbs == T * C:
+                L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+            else:
+                flat = tokens.reshape(-1)
+                L.tcl_tome_normalize_f16(flat, metric, T, C, stream())
+                L.tcl_tome_normalize_f16(flat[tbs:], metric[T * C:], T, C, stream())
         need = L.tcl_tome_match_workspace_bytes(na)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)        # zeroed once; every match leaves it zero again
@@ -157,11 +162,11 @@ class VidToMe:
         mrg = torch.empty(shape, dtype=I32, device=self.dev)
         unm = torch.empty((T,) if aligned else (2, T), dtype=I32, device=self.dev)
         for b in range(1 if aligned else 2):                                    # aligned: ONE matching over both entries (scores concatenated along dst)
-            mt, mo, uo, Bt = (metric, mrg, unm, 2) if aligned else (metric[b * T:], mrg[b], unm[b], 1)
+            mt, mo, uo, Bt = (metric, mrg, unm, 2) if aligned else (metric[b * mbs:], mrg[b], unm[b], 1)
             if affine is not None:
-                L.tcl_tome_match_affine_f16(mt, T * C, Bt, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mo, uo, self._ws, stream())
+                L.tcl_tome_match_affine_f16(mt, mbs, Bt, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mo, uo, self._ws, stream())
             else:
-                L.tcl_tome_match_f16(mt, T * C, Bt, C, a_pos, na, b_pos, nb, r, mo, uo, self._ws, stream())
+                L.tcl_tome_match_f16(mt, mbs, Bt, C, a_pos, na, b_pos, nb, r, mo, uo, self._ws, stream())
         return mrg, unm, na - r + nb
 
     # ---- patch.py:14-91
@@ -171,9 +176,10 @@ class VidToMe:
             return False
         return int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N))) <= self.args["max_downsample"]
 
-    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None):
+    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None, metric=None):
         """x: norm1 output of one chunk: the unconditional [F*N, C] rows at x, the conditional ones xbs elements further (default
-        F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]).  Returns None when this block is not merged, else
+        F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]); metric: x's cosine-normalised rows in the same layout if norm1 wrote them
+        (unet.py: tcl_layernorm_metric_f16), else None.  Returns None when this block is not merged, else
         (merged [2,T,C], unm int32 [F*N] ([2, F*N] without align_batch) or None for identity, T)."""
         a = self.args
         if not self.merges(N):
@@ -189,7 +195,7 @@ class VidToMe:
             a_pos, b_pos = self._positions(cur, N, randf, unm_pre)
             single = unm_pre == 0 and cur <= a["target_stride"]                # dst = the N tokens of frame randf, src = the rest: affine
             mrg, unm, Tn = self._match(seq, T, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=sbs,
-                                       affine=(randf * N, N, randf * N) if single else None)
+                                       affine=(randf * N, N, randf * N) if single else None, metric=metric if seq is x else None)
             nxt = torch.empty(2, Tn, C, dtype=H16, device=self.dev)
             self._gather(seq, sbs, mrg, nxt, Tn * C, Tn, C)
             if mrg1 is None:

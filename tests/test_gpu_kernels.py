@@ -100,6 +100,12 @@ def test_layernorm_geglu_softmax_gemv(L):
         y = torch.empty_like(x)
         L.tcl_layernorm_f16(x, ga, be, y, 999, C, 1e-5, st())
         assert rel(y, F.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5)) < 2e-3
+        # norm1 of a VidToMe-patched block writes the matching metric as well: same y, and the metric the matching would have computed
+        # from y itself (tcl_tome_normalize_f16), bit for bit -- the maps cannot depend on which kernel normalised
+        y2, m2, m = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        L.tcl_layernorm_metric_f16(x, ga, be, y2, m2, 999, C, 1e-5, st())
+        L.tcl_tome_normalize_f16(y, m, 999, C, st())
+        assert torch.equal(y2, y) and torch.equal(m2, m)
     x = torch.randn(500, 2560, device="cuda", generator=g).to(H)
     y = torch.empty(500, 1280, device="cuda", dtype=H)
     L.tcl_geglu_f16(x, y, 500, 1280, st())
@@ -324,12 +330,13 @@ def test_gemm_fused_geglu(L):
     assert rel(out, f[:, :4 * C] * F.gelu(f[:, 4 * C:])) < 2e-3
 
 
-@pytest.mark.parametrize("shape", [("g", 5520, 1280, 1280), ("g", 21600, 640, 640), ("g", 1472, 1280, 2560), ("c", 8, 23, 30, 640, 640),
-                                   ("c", 8, 4, 12, 1280, 1280)])
+@pytest.mark.parametrize("shape", [("g", 5520, 1280, 1280), ("g", 21600, 640, 640), ("g", 1472, 1280, 2560), ("g", 33333, 960, 320),
+                                   ("g", 20001, 352, 320), ("c", 8, 23, 30, 640, 640), ("c", 8, 4, 12, 1280, 1280)])
 def test_gemm_configs_bit_identical(L, shape):
     """Every tile configuration (LDS-DMA 128x128 / 64x128 / 128x64 / 64x64 / 256x128 and the 8-wave 256x320 / 128x320 / 256x256 /
-    128x256 kernels) accumulates each output in the same k order, so with equal K splits the results are bit-identical -- the
-    property the automatic configuration choice relies on -- and the automatic choice itself matches them."""
+    128x256 kernels; for K = 320 the strip-resident Linear of csrc/linstrip.hip, cfg 12, whose MFMA operand roles are swapped)
+    accumulates each output in the same k order, so with equal K splits the results are bit-identical -- the property the automatic
+    configuration choice relies on -- and the automatic choice itself matches them."""
     ws = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
     L.tcl_set_workspace(ws, ws.numel())
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -358,15 +365,15 @@ def test_gemm_configs_bit_identical(L, shape):
     try:
         for splits in (1, 4):
             outs = {}
-            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8):
-                if splits > 1 and cfg in (5, 6, 7, 8):
+            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8, 12):
+                if splits > 1 and cfg in (5, 6, 7, 8, 12):
                     continue
                 L.tcl_gemm_tune(cfg, splits)
                 try:
                     outs[cfg] = run()
                 except RuntimeError:          # configuration not applicable to this shape
                     continue
-            assert len(outs) >= 4
+            assert len(outs) >= 4 and (splits > 1 or shape[0] != "g" or shape[3] != 320 or 12 in outs)
             first = next(iter(outs.values()))
             assert rel(first, ref) < 2e-3
             for cfg, o in outs.items():
@@ -393,7 +400,7 @@ def test_gemm_fused_geglu_configs(L):
     ref = f[:, :4 * C] * F.gelu(f[:, 4 * C:])
     outs = {}
     try:
-        for cfg in (1, 2, 3, 4, 11, 7, 8):
+        for cfg in (1, 2, 3, 4, 11, 7, 8, 12):
             L.tcl_gemm_tune(cfg, 1)
             out = torch.empty(M, 4 * C, device="cuda", dtype=H)
             L.tcl_gemm_f16(A, Wg, bg, 0, out, M, 8 * C, C, C, C, 4 * C, 8 * C, 2, st())

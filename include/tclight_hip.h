@@ -42,6 +42,10 @@ int tcl_ms_ssim_loss(const float* X, const float* Y, int planes, int h, int w, f
 int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float* value, float* grad, void* ws16, hipStream_t st);
 /* torch.optim.Adam single-tensor step (generate.py:381,483-487); g is consumed and zeroed. step counts from 1. */
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
+/* How the flow term scatters d(loss)/d(warped previous frame) (generate.py:420-427 / :507-514 backward): 1 (default) = through an LDS window per
+ * 64x16 pixel tile, flushed once; 0 = every addend straight to global memory.  Integer (fixed-point) sums either way: same bits when W % 64 == 0,
+ * the same value up to the f32 rounding of differently grouped partial sums otherwise.  Test / A-B hook (env TCL_FLOW_TILED sets the initial mode). */
+int tcl_flow_scatter_mode(int tiled);
 /* Are the track ids of every frame pairwise distinct (true of get_flowid's output, utils/flow_utils.py:56-93: a pixel of frame i takes the id
  * of ONE pixel of frame i-1 or a fresh id)?  *result (device int) <- 1 / 0; scratch: K ints.  Stage 2 then accumulates codebook rows one frame
  * at a time without atomics -- bit-reproducible -- by passing ids_unique = 1 below; with 0 it falls back to float atomics (any id layout). */

@@ -14,6 +14,7 @@
 #include "../../include/tclight_hip.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 #define SH_C0 0.28209479177387814f
@@ -361,10 +362,99 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
 // flow-consistency term (generate.py:420-427): warp(pre)*m vs img*m, fwd + bwd fused.
 // images = cat[0..b), pre = cat[b..2b).  gimg [b,3,P] gets '-=' (owner pixel); the scatter into the previous frame's gradient goes to
 // gpre [b,3,P] in fixed point, UNSCALED (sign * mask * bicubic weight; the consumer multiplies by scale / FX_FLOW): integer atomics.
-__global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
-                            const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
-                            fx_t* __restrict__ gpre, fx_t* __restrict__ acc) {
+// Round 3, second half: the scatter goes through an LDS window.  A block owns a FT_W x FT_H pixel tile; the taps of a smooth flow field land in
+// the tile shifted by the flow plus the bicubic extent, so the block accumulates them in a (FT_W + 3 + slack) x (FT_H + 3 + slack) x 3
+// window of 64-bit LDS cells placed at the minimum tap origin of the tile, and flushes the non-zero cells once: ~5 global atomics per pixel
+// instead of 12, every one of them to consecutive cells of a row.  Taps outside the window (flow discontinuities) go to global memory
+// directly.  Integer sums: the result does not depend on which way an addend took, nor on the order -- and with W % 64 == 0 the waves
+// cover the same 64-pixel row segments as the untiled form (TILED == false, kept for A/B: TCL_FLOW_TILED=0), so the two agree bit for bit.
+#define FT_W 64
+#define FT_H 16
+#define FT_SL 5
+#define FT_WX (FT_W + 3 + FT_SL)
+#define FT_WY (FT_H + 3 + FT_SL)
+struct FlowWin { unsigned long long* cells; int x0, y0; };
+template <bool TILED>
+__device__ __forceinline__ void flow_sink(const FlowWin& w, fx_t* __restrict__ gp, int c, int P, int W, int yy, int xx, float v) {
+    const unsigned long long q = (unsigned long long)__float2ll_rn(v * FX_FLOW);
+    if (TILED) {
+        const int lx = xx - w.x0, ly = yy - w.y0;
+        if ((unsigned)lx < (unsigned)FT_WX && (unsigned)ly < (unsigned)FT_WY) { atomicAdd(w.cells + (c * FT_WY + ly) * FT_WX + lx, q); return; }
+    }
+    atomicAdd((unsigned long long*)(gp + (size_t)c * P + (size_t)yy * W + xx), q);
+}
+// one pixel (x, y) of cat row j: forward term, owner-pixel gradient, scatter of the pre-image gradient.  Returns sum_c |d|.
+template <bool TILED>
+__device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const float* __restrict__ pre, const float* __restrict__ fl,
+                                            const float* __restrict__ mk, float* __restrict__ gi, fx_t* __restrict__ gp, const FlowWin& win,
+                                            int x, int y, bool live, int lane, int H, int W, float scale) {
+    const int P = H * W;
+    const int pc = live ? y * W + x : P - 1;
+    if (!live) { y = (P - 1) / W; x = P - 1 - y * W; }
+    Tap t = make_tap(fl[pc], fl[P + pc], x, y, W, H);
+    const float m = live ? mk[pc] : 0.f;
+    float wv[3] = {0.f, 0.f, 0.f}, s = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
+            float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
+            wv[0] += wt * pre[a]; wv[1] += wt * pre[P + a]; wv[2] += wt * pre[2 * P + a];
+        }
+    }
+    float gw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float d = wv[c] * m - img[c * P + pc] * m;
+        s += fabsf(d);
+        gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m;              // 0 on dead lanes (m = 0); unscaled
+        if (live) gi[c * P + pc] -= gw[c] * scale;
+    }
+    // Scatter of d(loss)/d(warped) into the pre-image gradient: 16 taps x 3 channels per pixel.  Neighbouring pixels of a row whose taps
+    // share the integer offset (dx, dy) hit neighbouring cells: lane l's tap i and lane l+i's tap 0 are the SAME cell, so the four
+    // column taps are merged across lanes with shuffles and one add per (row, channel) is issued by the lane whose tap 0 owns the
+    // cell (12 adds per pixel instead of 48).  The merge is SEGMENTED by the class (y, dx, dy): a lane only absorbs taps of the
+    // lanes of its own class and emits itself the taps no successor of its class absorbs -- so a wave that straddles an integer crossing
+    // of a smooth flow field, a row end or the image end still takes this path (an earlier all-or-nothing version fell back to 48
+    // atomics per pixel for the whole wave at every such crossing: 12x slower on flows that hover around an integer).
+    const int dx = t.x0 - x, dy = t.y0 - y;
+    const int ca = live ? ((dx << 16) | (dy & 0xffff)) : (int)0x80000000, cb = live ? y : -1 - lane;
+    bool up[4], dn[4];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        // (all four shuffles unconditionally, combined with '&': a short-circuit '&&' would run them under a partial exec mask)
+        const int ua = __shfl_up(ca, i, 64), ub = __shfl_up(cb, i, 64), da = __shfl_down(ca, i, 64), db = __shfl_down(cb, i, 64);
+        up[i] = (lane >= i) & (ua == ca) & (ub == cb);          // lane l-i is of my class: I absorb its tap i
+        dn[i] = (lane + i <= 63) & (da == ca) & (db == cb);     // lane l+i is of my class: it absorbs my tap i
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int yy = t.y0 + jj;
+        const bool rowok = live && yy >= 0 && yy < H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float gwc = t.wy[jj] * gw[c];
+            const float v0 = gwc * t.wx[0], v1 = gwc * t.wx[1], v2 = gwc * t.wx[2], v3 = gwc * t.wx[3];
+            const float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
+            const float sum = v0 + (up[1] ? u1 : 0.f) + (up[2] ? u2 : 0.f) + (up[3] ? u3 : 0.f);
+            if (!rowok) continue;
+            if (t.x0 >= 0 && t.x0 < W && sum != 0.f) flow_sink<TILED>(win, gp, c, P, W, yy, t.x0, sum);
+            if (!dn[1] && v1 != 0.f && t.x0 + 1 >= 0 && t.x0 + 1 < W) flow_sink<TILED>(win, gp, c, P, W, yy, t.x0 + 1, v1);
+            if (!dn[2] && v2 != 0.f && t.x0 + 2 >= 0 && t.x0 + 2 < W) flow_sink<TILED>(win, gp, c, P, W, yy, t.x0 + 2, v2);
+            if (!dn[3] && v3 != 0.f && t.x0 + 3 >= 0 && t.x0 + 3 < W) flow_sink<TILED>(win, gp, c, P, W, yy, t.x0 + 3, v3);
+        }
+    }
+    return s;
+}
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
+                                                   const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
+                                                   fx_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x) {
     __shared__ float red[16];
+    __shared__ int wmin[2];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long fwin[];
     const int j = blockIdx.y, f = idx[j], P = H * W;
     if (f == 0) return;  // valid = idx > 0
     const float* img = cat + (size_t)j * 3 * P; const float* pre = cat + (size_t)(b + j) * 3 * P;
@@ -372,71 +462,56 @@ __global__ void k_flow_loss(const float* __restrict__ cat, const int* __restrict
     const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
-    // every lane of a wave runs the same trip count (the shuffles below need all 64 lanes); lanes past the image are `live == false`
-    for (int p0 = blockIdx.x * blockDim.x; p0 < P; p0 += gridDim.x * blockDim.x) {
-        const int p = p0 + threadIdx.x;
-        const bool live = p < P;
-        const int pc = live ? p : P - 1;
-        const int y = pc / W, x = pc - y * W;
-        Tap t = make_tap(fl[pc], fl[P + pc], x, y, W, H);
-        const float m = live ? mk[pc] : 0.f;
-        float wv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
-                float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
-                wv[0] += wt * pre[a]; wv[1] += wt * pre[P + a]; wv[2] += wt * pre[2 * P + a];
-            }
+    FlowWin win = {fwin, 0, 0};
+    if (!TILED) {
+        // every lane of a wave runs the same trip count (the shuffles need all 64 lanes); lanes past the image are `live == false`
+        for (int p0 = blockIdx.x * blockDim.x; p0 < P; p0 += gridDim.x * blockDim.x) {
+            const int p = p0 + threadIdx.x;
+            const bool live = p < P;
+            const int y = (live ? p : P - 1) / W, x = (live ? p : P - 1) - y * W;
+            s += flow_pixel<false>(img, pre, fl, mk, gi, gp, win, x, y, live, lane, H, W, scale);
         }
-        float gw[3];
+    } else {
+        const int X0 = ((int)blockIdx.x % tiles_x) * FT_W, Y0 = ((int)blockIdx.x / tiles_x) * FT_H, wv = threadIdx.x >> 6;
+        for (int i = threadIdx.x; i < 3 * FT_WY * FT_WX; i += 256) fwin[i] = 0ull;
+        if (threadIdx.x < 2) wmin[threadIdx.x] = 0x7fffffff;
+        __syncthreads();
+        int mx = 0x7fffffff, my = 0x7fffffff;                     // minimum tap origin of the tile's live pixels: the window's corner
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float d = wv[c] * m - img[c * P + pc] * m;
-            s += fabsf(d);
-            gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m;              // 0 on dead lanes (m = 0); unscaled
-            if (live) gi[c * P + p] -= gw[c] * scale;
-        }
-        // Scatter of d(loss)/d(warped) into the pre-image gradient: 16 taps x 3 channels per pixel.  Neighbouring pixels of a row whose taps
-        // share the integer offset (dx, dy) hit neighbouring cells: lane l's tap i and lane l+i's tap 0 are the SAME cell, so the four
-        // column taps are merged across lanes with shuffles and one atomic per (row, channel) is issued by the lane whose tap 0 owns the
-        // cell (12 atomics per pixel instead of 48).  The merge is SEGMENTED by the class (y, dx, dy): a lane only absorbs taps of the
-        // lanes of its own class and emits itself the taps no successor of its class absorbs -- so a wave that straddles an integer crossing
-        // of a smooth flow field, a row end or the image end still takes this path (an earlier all-or-nothing version fell back to 48
-        // atomics per pixel for the whole wave at every such crossing: 12x slower on flows that hover around an integer).
-        const int dx = t.x0 - x, dy = t.y0 - y;
-        const int ca = live ? ((dx << 16) | (dy & 0xffff)) : (int)0x80000000, cb = live ? y : -1 - lane;
-        bool up[4], dn[4];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            // (all four shuffles unconditionally, combined with '&': a short-circuit '&&' would run them under a partial exec mask)
-            const int ua = __shfl_up(ca, i, 64), ub = __shfl_up(cb, i, 64), da = __shfl_down(ca, i, 64), db = __shfl_down(cb, i, 64);
-            up[i] = (lane >= i) & (ua == ca) & (ub == cb);          // lane l-i is of my class: I absorb its tap i
-            dn[i] = (lane + i <= 63) & (da == ca) & (db == cb);     // lane l+i is of my class: it absorbs my tap i
+        for (int r = 0; r < FT_H / 4; ++r) {
+            const int x = X0 + lane, y = Y0 + r * 4 + wv;
+            if (x < W && y < H) { Tap t = make_tap(fl[y * W + x], fl[P + y * W + x], x, y, W, H); mx = min(mx, t.x0); my = min(my, t.y0); }
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int yy = t.y0 + jj;
-            const bool rowok = live && yy >= 0 && yy < H;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float gwc = t.wy[jj] * gw[c];
-                const float v0 = gwc * t.wx[0], v1 = gwc * t.wx[1], v2 = gwc * t.wx[2], v3 = gwc * t.wx[3];
-                const float u1 = __shfl_up(v1, 1, 64), u2 = __shfl_up(v2, 2, 64), u3 = __shfl_up(v3, 3, 64);
-                const float sum = v0 + (up[1] ? u1 : 0.f) + (up[2] ? u2 : 0.f) + (up[3] ? u3 : 0.f);
-                if (!rowok) continue;
-                fx_t* row = gp + (size_t)c * P + (size_t)yy * W;
-                if (t.x0 >= 0 && t.x0 < W && sum != 0.f) fx_add(row + t.x0, sum, FX_FLOW);
-                if (!dn[1] && v1 != 0.f && t.x0 + 1 >= 0 && t.x0 + 1 < W) fx_add(row + t.x0 + 1, v1, FX_FLOW);
-                if (!dn[2] && v2 != 0.f && t.x0 + 2 >= 0 && t.x0 + 2 < W) fx_add(row + t.x0 + 2, v2, FX_FLOW);
-                if (!dn[3] && v3 != 0.f && t.x0 + 3 >= 0 && t.x0 + 3 < W) fx_add(row + t.x0 + 3, v3, FX_FLOW);
+        for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_xor(mx, o, 64)); my = min(my, __shfl_xor(my, o, 64)); }
+        if (lane == 0) { atomicMin(&wmin[0], mx); atomicMin(&wmin[1], my); }
+        __syncthreads();
+        win.x0 = wmin[0]; win.y0 = wmin[1];
+#pragma unroll 1
+        for (int r = 0; r < FT_H / 4; ++r) {
+            const int x = X0 + lane, y = Y0 + r * 4 + wv;
+            s += flow_pixel<true>(img, pre, fl, mk, gi, gp, win, x, y, x < W && y < H, lane, H, W, scale);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * FT_WY * FT_WX; i += 256) {
+            const unsigned long long v = fwin[i];
+            if (v) {
+                const int c = i / (FT_WY * FT_WX), rem = i - c * (FT_WY * FT_WX), ly = rem / FT_WX, lx = rem - ly * FT_WX;
+                atomicAdd((unsigned long long*)(gp + (size_t)c * P + (size_t)(win.y0 + ly) * W + win.x0 + lx), v);
             }
         }
     }
     float r = block_sum(s, red);
     if (threadIdx.x == 0) fx_add(acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4 + 3, r, FX_ACC);
+}
+static int g_flow_tiled = -1;
+static void launch_flow_loss(const float* cat, const int* cidx, const float* flows, const float* masks, int b, int H, int W, float fscale, float* gimg,
+                             fx_t* gpre, fx_t* acc, dim3 untiled_grid, hipStream_t st) {
+    if (g_flow_tiled < 0) g_flow_tiled = getenv("TCL_FLOW_TILED") ? atoi(getenv("TCL_FLOW_TILED")) : 1;      // A/B hook: 0 = global atomics only
+    if (g_flow_tiled) {
+        const int tx = cdiv(W, FT_W), ty = cdiv(H, FT_H);
+        hipLaunchKernelGGL(k_flow_loss<true>, dim3(tx * ty, b), dim3(256), (size_t)3 * FT_WY * FT_WX * 8, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, tx);
+    } else hipLaunchKernelGGL(k_flow_loss<false>, untiled_grid, dim3(256), 0, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, 0);
 }
 // loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
 __global__ void k_loss_finalize(fx_t* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
@@ -488,14 +563,18 @@ __device__ __forceinline__ void adam_replay(float (&p)[3], float (&m)[3], float 
         for (int c = 0; c < 3; ++c) adam_elem(p[c], m[c], v[c], 0.f, lr, b1, b2, eps, c1, c2);
     }
 }
-// rows of cat row j: bring them to step `upto` (no gradient)
-__global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int j, int P, size_t K, int* __restrict__ t_last,
+// rows of the cat rows blockIdx.y (all frames of a mini-batch in ONE launch): bring them to step `upto` (no gradient).  A track that several
+// frames of the batch share is claimed by exactly one thread (atomicMax on its step counter returns the old value to the first comer only);
+// whoever wins computes the same values, nobody else touches the row in this launch, and its readers are later kernels: same bits as the
+// frame-by-frame launches this replaces (32 launches of ~34 us per iteration at batch 16).
+__global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                      float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto, float lr, float b1, float b2,
                                      float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
-    const int* iv = inv + (size_t)fidx[j] * P;
+    const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        const int tl = t_last[id];
+        if (t_last[id] >= upto) continue;
+        const int tl = atomicMax(t_last + id, upto);
         if (tl >= upto) continue;
         float pp[3], mm[3], vv[3];
 #pragma unroll
@@ -503,24 +582,23 @@ __global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __r
         adam_replay(pp, mm, vv, tl + 1, upto, lr, b1, b2, eps, bc1, bc2);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { p[c * K + id] = pp[c]; m[c * K + id] = mm[c]; v[c * K + id] = vv[c]; }
-        t_last[id] = upto;
     }
 }
-// rows of cat row j that stand at step - 1: apply `step` with their gradient, clear it
-__global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int j, int P, size_t K, int* __restrict__ t_last,
+// rows of the cat rows blockIdx.y that stand at step - 1: apply `step` with their (complete) gradient, clear it.  One thread per row wins the
+// compare-and-swap of the step counter.
+__global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                      float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
                                      float b1, float b2, float eps, float bc1, float bc2_sqrt) {
-    const int* iv = inv + (size_t)fidx[j] * P;
+    const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        if (t_last[id] != step - 1) continue;            // already stepped by an earlier frame of this mini-batch
+        if (t_last[id] != step - 1 || atomicCAS(t_last + id, step - 1, step) != step - 1) continue;      // stepped by another frame of this mini-batch
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float pi = p[c * K + id], mi = m[c * K + id], vi = v[c * K + id];
             adam_elem(pi, mi, vi, g[c * K + id], lr, b1, b2, eps, bc1, bc2_sqrt);
             p[c * K + id] = pi; m[c * K + id] = mi; v[c * K + id] = vi; g[c * K + id] = 0.f;
         }
-        t_last[id] = step;
     }
 }
 // end of the stage: every row to the last step
@@ -559,6 +637,9 @@ static inline dim3 pgrid(int P, int ny) { return dim3(stream_grid(P, 256, 4) > 1
 static inline int pooled(int s) { return (s + 2 * (s & 1) - 2) / 2 + 1; }
 
 extern "C" {
+
+int tcl_flow_scatter_mode(int tiled) { g_flow_tiled = tiled; return TCL_OK; }
+
 
 int tcl_warp_flow_fwd(const float* img, const float* flow, float* out, int n, int c, int h, int w, int flow_c, hipStream_t st) {
     TCL_CHECK_ARG(img && flow && out && n > 0 && c > 0 && h > 1 && w > 1 && flow_c >= 2);
@@ -728,7 +809,7 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
     if (hipMemsetAsync(S.efx, 0, (size_t)2 * b * 12 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
-    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc);
+    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), st);
     // 64 blocks per row (each block ends in 12 block-wide sums + 12 atomics: with the P / 1024-pixel blocks of the other kernels this was the
     // slowest kernel of stage 1), partial sums in fixed point, rows added to the gradient in order
     hipLaunchKernelGGL(k_exposure_bwd, dim3(64, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gimg, S.gpre, fscale / FX_FLOW, b, S.efx, (int)P);
@@ -757,7 +838,7 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
-    hipLaunchKernelGGL(k_flow_loss, pgrid(P, b), dim3(256), 0, st, S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc);
+    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), st);
     if (ids_unique)          // one cat row per launch, in order: conflict-free read-modify-write of the rows' gradients, no atomics
         for (int j = 0; j < 2 * b; ++j)
             hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale / FX_FLOW, b, j, g, (int)P, K);
@@ -821,18 +902,16 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
         const int* cidx = d_cat + (size_t)it * 2 * batch;
-        if (lazy)       // the mini-batch's rows catch up with the steps they skipped (1 .. it), frame by frame, before they are gathered
-            for (int j = 0; j < 2 * b; ++j)
-                hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 1), dim3(256), 0, st, unq_inv, cidx, j, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,
-                                   1e-15f, bc1, bc2);
+        if (lazy)       // the mini-batch's rows catch up with the steps they skipped (1 .. it) before they are gathered
+            hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,
+                               1e-15f, bc1, bc2);
         int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
                                         lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
         if (rc) return rc;
         if (lazy) {
             const float c1 = (float)(1.0 - pow((double)0.9f, it + 1)), c2 = (float)sqrt(1.0 - pow((double)0.999f, it + 1));
-            for (int j = 0; j < 2 * b; ++j)
-                hipLaunchKernelGGL(k_adam_touched_frame, pgrid(P, 1), dim3(256), 0, st, unq_inv, cidx, j, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
-                                   0.999f, 1e-15f, c1, c2);
+            hipLaunchKernelGGL(k_adam_touched_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
+                               0.999f, 1e-15f, c1, c2);
         } else {
             rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
             if (rc) return rc;

@@ -139,6 +139,38 @@ def test_stage1_stage2_bit_reproducible(ops):
     assert torch.isfinite(out_d).all() and torch.isfinite(l2d).all()
 
 
+def test_flow_scatter_lds_window_equals_global(ops):
+    """The flow term's gradient scatter through the per-tile LDS window (default) against every addend straight to global memory: fixed-point
+    integer sums, so at W % 64 == 0 (same 64-pixel wave segments) stage 1 + stage 2 agree BIT FOR BIT -- also where the flow jumps by more than
+    the window's slack (a tear of 40 px through the frame: those taps leave the window and take the global path) -- and at another width
+    the two agree to the f32 rounding of differently grouped partial sums."""
+    from tc_light_amd.lib import lib
+    L = lib()
+    for (h, w), exact in (((192, 256), True), ((176, 200), False)):
+        d = synth.video_clip(5, h, w, seed=31, shift=(2.3, -1.6))
+        fl = d["past_flows"].clone()
+        fl[:, 0, :, w // 2:] += 40.0                                # discontinuity: right half moves 40 px further
+        fl[:, 1, h // 3:h // 3 + 7] -= 23.0
+        inv, k = synth.track_ids(5, h, w, seed=8)
+        bts1, bts2 = synth.batches(5, 2, epochs=2, seed=2), synth.batches(5, 2, epochs=3, seed=3)
+        res = []
+        try:
+            for mode in (0, 1):
+                L.tcl_flow_scatter_mode(mode)
+                ds = ops.OptDataset(d["edited"], fl, d["masks"], device="cuda")
+                al, expo, l1 = ops.exposure_align(ds, bts1, epochs=2, batch_size=2)
+                out, feat, l2 = ops.unique_tensor_optimization(ds, inv.cuda(), bts2, batch_size=2, k=k)
+                torch.cuda.synchronize()
+                res.append([t.detach().clone() for t in (expo, l1, out, l2)])
+        finally:
+            L.tcl_flow_scatter_mode(1)
+        for a, b, name in zip(res[0], res[1], ("exposure", "losses 1", "relit", "losses 2")):
+            if exact:
+                assert torch.equal(a, b), (name, h, w)
+            else:
+                assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0), (name, h, w)
+
+
 def test_stage2_lazy_adam_equals_dense(ops, monkeypatch):
     """The reference's Adam over the codebook is dense (every row moves every iteration through its momentum).  The lazy schedule only visits
     the rows of the mini-batch's frames and replays the gradient-free steps a row skipped right before it is needed; it must reproduce the dense

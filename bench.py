@@ -388,9 +388,13 @@ def main():
             t_it = info["timing"]["stage2"] / it2
             it1 = a.epochs_exposure * (-(-n_total // cfg["batch_size"]))
             res["roofline_path2"] = {"bound": "hbm", "kernel": "stage-2 iteration (unique-tensor optimisation: codebook gather, MS-SSIM / TV / flow losses + "
-                                     "gradients, frame-ordered codebook gradient, dense Adam over all K rows)", "achieved": by2 / t_it / 1e9, "peak": 8000.0,
+                                     "gradients, frame-ordered codebook gradient, Adam over all K rows)", "achieved": by2 / t_it / 1e9, "peak": 8000.0,
                                      "unit": "GB/s", "frac": by2 / t_it / 8e12, "traffic": None, "iterations": it2, "ms_per_iteration": t_it * 1e3,
                                      "algorithmic_bytes_per_iteration": by2,
+                                     "adam_schedule": ("lazy" if int(K) > 3 * 2 * cfg["batch_size"] * H * W else "dense"),
+                                     "note": "`achieved` credits the reference algorithm's bytes (84 B per codebook row and iteration for its dense Adam); "
+                                             "with the lazy schedule (bit-identical results) rows outside the mini-batch are not moved, so this is an effective "
+                                             "rate, not HBM traffic",
                                      "stage1": {"ms_per_iteration": info["timing"]["stage1"] / max(it1, 1) * 1e3, "iterations": it1,
                                                 "achieved": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 1e9,
                                                 "frac": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 8e12},

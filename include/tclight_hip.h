@@ -138,6 +138,12 @@ int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st);
 /* The same, plus metric = y / |y| per row with tcl_tome_normalize_f16's f16 arithmetic (norm1 of a VidToMe-patched block, patch.py:161-166 ->
  * merge.py:84: the matching metric of the block's tokens, produced while they are in registers). */
+/* C = act(LayerNorm(x; gamma, beta, eps) . W^T + bias) (+ resid): norm2 -> attn2.to_q and norm3 -> ff.net.0 (GEGLU, act 2) of BasicTransformerBlock
+ * (generate.py:342-347 -> diffusers) in one kernel, for K = 320 (the level-0 blocks; other widths: tcl_layernorm_f16 + tcl_gemm_f16).  The
+ * normalised activations are rounded to f16 exactly as tcl_layernorm_f16 rounds them; the f32 statistics are summed in another order (not bit-identical
+ * to the two-kernel route, 1e-3 rel-L2 like any two f16 LayerNorms).  N >= 128, N % 32 == 0 (GEGLU: % 64), 16-B aligned rows. */
+int tcl_ln_gemm_f16(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias, const void* resid, void* C,
+                    int M, int N, int K, int ldx, int ldw, int ldc, int ldr, int act, hipStream_t st);
 int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st);
 /* diffusers GEGLU: in [rows, 2D] -> out [rows, D] = in[:, :D] * gelu(in[:, D:]) (exact erf gelu). */
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st);

@@ -49,4 +49,5 @@ int gemm8_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16
 // strip-resident K = 320 Linear (linstrip.hip), cfg 12
 bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp);
 int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
-                       int lda, int ldw, int ldc, int ldr, int act, hipStream_t st);
+                       int lda, int ldw, int ldc, int ldr, int act, hipStream_t st, const _Float16* gamma = nullptr, const _Float16* beta = nullptr,
+                       float eps = 0.f);

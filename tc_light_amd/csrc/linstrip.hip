@@ -37,11 +37,15 @@ __device__ __forceinline__ void ls_exchange(const _Float16 (&o)[16], uint4v& p0,
 #ifndef LS_ABL
 #define LS_ABL 0        // lab-only knock-outs (tools/micro/lin_lab.hip): 1 no C stores, 2 no A loads, 4 no residual loads, 8 no sweep (DMA + MFMA)
 #endif
-template <int K, int NW>
+// LN: the rows of A are LayerNorm-ed (gamma, beta, eps over the K = C elements) on their way into the B-operand registers -- the row is already
+// spread over the two lanes that hold it, so the statistics cost one lane exchange and the normalised activations never exist in memory
+// (tcl_ln_gemm_f16: norm2 -> to_q of attn2, norm3 -> GEGLU feed-forward of the C = 320 transformer blocks).
+template <int K, int NW, bool LN>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                                        const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                                        _Float16* __restrict__ C, int M, int N, int lda, int ldw, int ldc, int ldr,
-                                                                       int act, int tiles_n, int nsplit) {
+                                                                       int act, int tiles_n, int nsplit, const _Float16* __restrict__ gamma,
+                                                                       const _Float16* __restrict__ beta, float eps) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NST = K / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,6 +88,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _F
     for (int i = tid; i < ntl * 128; i += 64 * NW) {                              // bias of the swept tiles (the last tile is moved back, like its rows)
         const int n = min((t0 + i / 128) * 128, N - 128) + (i & 127);
         sbias[i] = bias ? bias[n] : (_Float16)0.f;
+    }
+    if (LN) {       // torch.nn.LayerNorm over the row: f32 statistics (two passes), f16 result -- under the latency of the first weight stages
+        float s1 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += (float)bfr[ks][j];
+        const float o1 = __shfl_xor(s1, 32, 64);
+        const float mean = (hl ? o1 + s1 : s1 + o1) / K;                          // lower half + upper half on both lanes
+        float s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)bfr[ks][j] - mean; s2 += d * d; }
+        const float o2 = __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf((hl ? o2 + s2 : s2 + o2) / K + eps);
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) {
+            const half8 g = *(const half8*)(gamma + ks * 16 + 8 * hl), bt = *(const half8*)(beta + ks * 16 + 8 * hl);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bfr[ks][j] = (_Float16)(((float)bfr[ks][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // bias in LDS before the first barrier
     int step = 0;
@@ -196,7 +222,7 @@ bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool 
 }
 
 int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
-                       int lda, int ldw, int ldc, int ldr, int act, hipStream_t st) {
+                       int lda, int ldw, int ldc, int ldr, int act, hipStream_t st, const _Float16* gamma, const _Float16* beta, float eps) {
     if (K != 320) return TCL_EINVAL;
     constexpr int NW = 4;
     const int tn = cdiv(N, 128), strips = cdiv(M, 32 * NW);
@@ -207,7 +233,24 @@ int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bia
     if (force_split > 0 && tn / force_split >= 1) nsplit = force_split;
     const size_t lds = (size_t)4 * 128 * 128 + (size_t)cdiv(tn, nsplit) * 128 * 2;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_lin_strip<320, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128 + 64 * 128 * 2); set = true; }
-    hipLaunchKernelGGL((k_lin_strip<320, NW>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit);
+    if (!set) {
+        (void)hipFuncSetAttribute((const void*)k_lin_strip<320, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128 + 64 * 128 * 2);
+        (void)hipFuncSetAttribute((const void*)k_lin_strip<320, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128 + 64 * 128 * 2);
+        set = true;
+    }
+    if (gamma) hipLaunchKernelGGL((k_lin_strip<320, NW, true>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps);
+    else hipLaunchKernelGGL((k_lin_strip<320, NW, false>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+extern "C" {
+#include "../../include/tclight_hip.h"
+int tcl_ln_gemm_f16(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias, const void* resid, void* C,
+                    int M, int N, int K, int ldx, int ldw, int ldc, int ldr, int act, hipStream_t st) {
+    TCL_CHECK_ARG(x && gamma && beta && W && C && M > 0 && act >= 0 && act <= 5 && (act != 2 || !resid));
+    ConvP cp = {};
+    TCL_CHECK_ARG(lin_strip_ok(M, N, K, ldx, ldw, ldc, ldr, resid != nullptr, act, cp) && ldx >= K && ldw >= K);
+    return lin_strip_dispatch((const _Float16*)x, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, ldx, ldw, ldc,
+                              ldr, act, st, (const _Float16*)gamma, (const _Float16*)beta, eps);
+}
 }

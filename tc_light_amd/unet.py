@@ -110,6 +110,14 @@ class Ops:
         self.L.tcl_layernorm_f16(x, gamma, beta, y, rows, C, 1e-5, stream())
         return y
 
+    def ln_gemm(self, x, gamma, beta, w, bias=None, act=0):
+        """act(LayerNorm(x) @ w.T + bias) in one kernel (K = 320: csrc/linstrip.hip); the normalised activations are never written."""
+        N, K = w.shape
+        M = x.numel() // K
+        c = self.empty(M, N // 2 if act == 2 else N)
+        self.L.tcl_ln_gemm_f16(x, gamma, beta, 1e-5, w, bias if bias is not None else 0, 0, c, M, N, K, K, K, c.shape[1], N, act, stream())
+        return c
+
     def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1):
         o = self.empty(B * Tq, Hh * d)
         wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
@@ -310,8 +318,8 @@ class UNetEngine:
             # (running the attention of alternate chunks on a second stream as well was measured: no further gain)
         F = Ftot
         # ---- attn2: text cross-attention on the full tokens
-        n2 = o.layernorm(h, *blk["ln"][1], M, C)
-        q = o.gemm(n2, blk["q2"])
+        fuse_ln = C == 320 and os.environ.get("TCL_LN_GEMM", "1") != "0"      # norm2 / norm3 ride in the consumer's operand load (strip-resident Linear)
+        q = o.ln_gemm(h, *blk["ln"][1], blk["q2"]) if fuse_ln else o.gemm(o.layernorm(h, *blk["ln"][1], M, C), blk["q2"])
         tk = self._text_kv(blk, text)
         Lt = tk["L"]
         a = o.attention(q, C, N * C, tk["kv"], 2 * C, Lt * 2 * C, tk["kv"][:, C:], 2 * C, Lt * 2 * C, B, Hd, N, Lt, d,
@@ -320,8 +328,10 @@ class UNetEngine:
         h = o.gemm(a, blk["o2"][0], blk["o2"][1], resid=h)
         self._fl(2.0 * M * C * C * 2 + 4.0 * M * Lt * C)
         # ---- GEGLU feed-forward
-        n3 = o.layernorm(h, *blk["ln"][2], M, C)
-        f2 = o.gemm(n3, blk["ff1"][0], blk["ff1"][1], act=2)            # Linear(C -> 8C) + GEGLU fused in the GEMM epilogue -> [M, 4C]
+        if fuse_ln:
+            f2 = o.ln_gemm(h, *blk["ln"][2], blk["ff1"][0], blk["ff1"][1], act=2)
+        else:
+            f2 = o.gemm(o.layernorm(h, *blk["ln"][2], M, C), blk["ff1"][0], blk["ff1"][1], act=2)   # Linear(C -> 8C) + GEGLU fused in the GEMM epilogue -> [M, 4C]
         h = o.gemm(f2, blk["ff2"][0], blk["ff2"][1], resid=h)
         self._fl(2.0 * M * C * C * 12)
         return o.gemm(h, blk["pout"][0], blk["pout"][1], resid=x)

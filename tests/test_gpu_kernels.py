@@ -387,6 +387,31 @@ def test_gemm_configs_bit_identical(L, shape):
     torch.cuda.synchronize()
 
 
+def test_ln_gemm_fused(L):
+    """LayerNorm folded into the strip-resident K = 320 Linear (tcl_ln_gemm_f16) against tcl_layernorm_f16 + tcl_gemm_f16 and against torch f32:
+    plain, bias + SiLU, GEGLU; M not a multiple of the 128-row strip."""
+    from tc_light_amd.unet import _geglu_rows
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M, C = 20011, 320
+    x = (torch.randn(M, C, device="cuda", generator=g) * 2 + 0.3).to(H)
+    ga, be = (1 + 0.2 * torch.randn(C, device="cuda", generator=g)).to(H), (0.1 * torch.randn(C, device="cuda", generator=g)).to(H)
+    y = torch.empty_like(x)
+    L.tcl_layernorm_f16(x, ga, be, y, M, C, 1e-5, st())
+    ref_ln = F.layer_norm(x.float(), (C,), ga.float(), be.float(), 1e-5)
+    for N, act, has_b in ((320, 0, False), (960, 1, True), (2560, 2, True)):
+        W = (torch.randn(N, C, device="cuda", generator=g) / C ** 0.5).to(H)
+        b = torch.randn(N, device="cuda", generator=g).to(H) if has_b else None
+        Wk, bk = (_geglu_rows(W).contiguous(), _geglu_rows(b).contiguous()) if act == 2 else (W, b)
+        No = N // 2 if act == 2 else N
+        two, one = torch.empty(M, No, device="cuda", dtype=H), torch.empty(M, No, device="cuda", dtype=H)
+        L.tcl_gemm_f16(y, Wk, bk if bk is not None else 0, 0, two, M, N, C, C, C, No, N, act, st())
+        L.tcl_ln_gemm_f16(x, ga, be, 1e-5, Wk, bk if bk is not None else 0, 0, one, M, N, C, C, C, No, N, act, st())
+        f = ref_ln @ W.float().t() + (b.float() if b is not None else 0)
+        ref = f[:, :N // 2] * F.gelu(f[:, N // 2:]) if act == 2 else (F.silu(f) if act == 1 else f)
+        assert rel(one, ref) < 2e-3 and rel(one, two.float()) < 1e-3, (N, act, rel(one, ref), rel(one, two.float()))
+        assert (one != two).float().mean().item() < 0.02          # same rounding points: only rows whose statistics differ in the last bit move
+
+
 def test_gemm_fused_geglu_configs(L):
     """GEGLU epilogue (64-row [32 value | 32 gate] groups) across tile configurations, incl. the 8-wave 256x256 / 128x256 kernels."""
     from tc_light_amd.unet import _geglu_rows

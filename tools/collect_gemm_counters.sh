@@ -44,3 +44,16 @@ echo "# k_gemm_dma<128,128> on lin 368640 x {320, 2560 GEGLU, 960} x 320: per-la
 python $GRAFT_REPO_ROOT/tools/micro/pmc_agg.py k_gemm_dmaILi128ELi128E /tmp/pg_*/p_counter_collection.csv >> $f
 summ $f
 tail -8 $OUT/gemm8p_counters_shape22.txt; tail -6 $f
+# strip-resident K = 320 Linear (cfg 12): the GEGLU feed-forward 368640 x 2560 x 320 (shape 5 of tools/micro/lin_lab)
+if [ -x $GRAFT_REPO_ROOT/tools/micro/bin/lin_lab ]; then
+LL=$GRAFT_REPO_ROOT/tools/micro/bin/lin_lab
+rm -rf /tmp/pg_*
+i=0
+for set in "${SETS[@]}"; do i=$((i+1)); rocprofv3 --pmc $set --output-format csv -d /tmp/pg_$i -o p -- $LL 5 > /tmp/pg_$i.log 2>&1 || tail -3 /tmp/pg_$i.log; done
+f=$OUT/lin_strip_counters.txt
+$LL 5 | grep -E "==|cfg 12|cfg  1:" > $f
+echo "# per-launch means over the k_lin_strip<320,4,false> launches of the lab run above" >> $f
+python $GRAFT_REPO_ROOT/tools/micro/pmc_agg.py k_lin_stripILi320E /tmp/pg_*/p_counter_collection.csv >> $f
+summ $f
+tail -8 $f
+fi

@@ -85,6 +85,10 @@ def read_frames(path):
         from PIL import Image, ImageSequence
         return torch.stack([torch.from_numpy(np.asarray(fr.convert("RGB")).copy()).permute(2, 0, 1).float() / 255.0
                             for fr in ImageSequence.Iterator(Image.open(path))])
+    if path.lower().endswith(".avi"):                        # Motion-JPEG AVI (what save_video writes here): own reader, no codec library
+        fr = read_mjpeg_avi(path)
+        if fr is not None:
+            return _to_nchw01(fr)
     try:
         import torchvision.io as tvio
         return tvio.read_video(path, pts_unit="sec", output_format="TCHW")[0].float() / 255.0
@@ -102,6 +106,62 @@ def read_frames(path):
     except ImportError:
         raise RuntimeError(f"no video decoder (torchvision.io / cv2) in this environment: convert {path} to a frame directory "
                            f"({'/'.join(FRAME_EXT)}) or a [N,H,W,3] uint8 .npy first")
+
+
+# ---- Motion-JPEG in an AVI container, written / read with nothing but PIL: the reference's save_video needs an H.264 encoder behind torchvision
+# (utils/VidToMe/utils.py:147-166) and this image has none; a relight must still come out as ONE playable file.  RIFF layout: hdrl (avih + one
+# 'vids' / 'MJPG' stream), movi ('00dc' chunks, one JPEG per frame), idx1.
+def write_mjpeg_avi(dst, frames_u8, fps=30, quality=95):
+    """frames_u8: uint8 [N,H,W,3] (numpy or tensor)."""
+    import io
+    import struct
+    from PIL import Image
+    fr = frames_u8.numpy() if isinstance(frames_u8, torch.Tensor) else np.asarray(frames_u8)
+    n, h, w = fr.shape[:3]
+    jpgs = []
+    for f in fr:
+        b = io.BytesIO()
+        Image.fromarray(f).save(b, format="JPEG", quality=quality, subsampling=0)
+        jpgs.append(b.getvalue())
+    chunk = lambda cc, data: cc + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+    lst = lambda kind, data: b"LIST" + struct.pack("<I", len(data) + 4) + kind + data
+    us = int(round(1e6 / max(fps, 1)))
+    biggest = max(len(j) for j in jpgs)
+    avih = struct.pack("<14I", us, biggest * max(int(fps), 1), 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, 1, max(int(fps), 1), 0, n, biggest, 0xFFFFFFFF, 0, 0, 0, w, h)
+    strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi, idx, off = b"", b"", 4
+    for j in jpgs:
+        c = chunk(b"00dc", j)
+        idx += b"00dc" + struct.pack("<III", 0x10, off, len(j))
+        movi += c
+        off += len(c)
+    body = b"AVI " + hdrl + lst(b"movi", movi) + chunk(b"idx1", idx)
+    with open(dst, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def read_mjpeg_avi(path):
+    """-> uint8 tensor [N,H,W,3], or None when the file is not a RIFF AVI whose video stream is (M)JPEG."""
+    import io
+    import struct
+    from PIL import Image
+    data = open(path, "rb").read()
+    if data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+        return None
+    out = []
+
+    def walk(lo, hi):
+        while lo + 8 <= hi:
+            cc, sz = data[lo:lo + 4], struct.unpack("<I", data[lo + 4:lo + 8])[0]
+            if cc == b"LIST":
+                walk(lo + 12, lo + 8 + sz)
+            elif cc[2:] in (b"dc", b"db") and sz > 2 and data[lo + 8:lo + 10] == b"\xff\xd8":
+                out.append(torch.from_numpy(np.asarray(Image.open(io.BytesIO(data[lo + 8:lo + 8 + sz])).convert("RGB")).copy()))
+            lo += 8 + sz + (sz & 1)
+    walk(12, len(data))
+    return torch.stack(out) if out else None
 
 
 def save_frames(frames, path, ext="png", frame_ids=None):
@@ -159,11 +219,21 @@ def save_video(frames, path, frame_ids=None, save_frame=False, gif=True, post_fi
                 print(f"[WARN] {writer.__name__[1:]} failed ({type(e).__name__}: {e}); trying the next writer")
             if os.path.exists(dst):
                 os.remove(dst)
-    if out is None:                                    # no encoder in this image: keep the data, say so
+    if out is None and not gif:                        # no H.264 encoder: one playable file all the same (Motion-JPEG AVI through PIL)
+        try:
+            out = os.path.join(path, f"output{post_fix}.avi")
+            write_mjpeg_avi(out, proc, fps=fps)
+            print(f"[INFO] no H.264 encoder (torchvision / cv2) in this environment: wrote Motion-JPEG {out} instead of output{post_fix}.mp4")
+        except Exception as e:            # noqa: BLE001
+            print(f"[WARN] mjpeg_avi failed ({type(e).__name__}: {e})")
+            if os.path.exists(out):
+                os.remove(out)
+            out = None
+    if out is None:                                    # no encoder at all: keep the data, say so
         out = os.path.join(path, f"output{post_fix}.npy")
         np.save(out, proc.numpy())
         save_frames(frames, os.path.join(path, f"frames{post_fix}"), frame_ids=ids)
-        print(f"[INFO] no working video encoder (torchvision / cv2 / imageio): wrote {out} and PNG frames instead of output{post_fix}.mp4")
+        print(f"[INFO] no working video encoder (torchvision / cv2 / imageio / PIL): wrote {out} and PNG frames instead of output{post_fix}.mp4")
     else:
         print(f"[INFO] save video to {out}")
     if save_frame:

@@ -180,6 +180,18 @@ def test_frame_directory_png_loader_and_writer(tmp_path):
     assert np.abs(back.astype(int) - src[1].astype(int)).max() <= 1
     gt = DP.save_video(fr, str(out), gif=False, post_fix="_gt")
     assert "output_gt" in os.path.basename(gt)
+    # whatever container came out (.mp4 with an H.264 encoder, else Motion-JPEG .avi written through PIL) reads back as the same clip
+    if path.endswith((".avi", ".mp4")):
+        rb = DP.read_frames(path)
+        assert rb.shape == fr.shape and (rb - fr.clamp(0, 1)).abs().mean() < 0.03
+    # the codec-free container on its own: RIFF AVI, one JPEG per frame, odd frame sizes, index chunk present
+    clip = (np.random.default_rng(0).random((4, 21, 35, 3)) * 255).astype(np.uint8)
+    DP.write_mjpeg_avi(str(tmp_path / "t.avi"), clip, fps=7, quality=98)
+    raw = open(tmp_path / "t.avi", "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and b"MJPG" in raw[:256] and b"idx1" in raw and int.from_bytes(raw[4:8], "little") == len(raw) - 8
+    rb = DP.read_mjpeg_avi(str(tmp_path / "t.avi"))
+    assert rb.shape == (4, 21, 35, 3) and np.abs(rb.numpy().astype(int) - clip.astype(int)).mean() < 12       # noise is JPEG's worst case
+    assert DP.read_mjpeg_avi(str(tmp_path / "dark.npy")) is None
     gif = DP.save_video(fr, str(out), gif=True)
     assert gif.endswith("output.gif") and DP.read_frames(gif).shape == (3, 3, 40, 60)
     DP.save_loss_curve([0.3, 0.2, 0.1], str(out), "loss_exposure")

@@ -314,7 +314,7 @@ def main():
     def one_pass(generator, profile=False):
         if profile:
             lib().tcl_flash_profile_begin(40)
-            unet.flops, unet.count_flops = 0.0, True
+            unet.flops, unet.flops_executed, unet.count_flops = 0.0, 0.0, True
         out, info = generator(frames, conds, conds_t, flows, masks, inv, n_total=n_total, k=K)
         prof = None
         if profile:
@@ -377,6 +377,8 @@ def main():
                          "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
                          "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": unet.flops / 1e12,
+                         "unet_executed_tflop_per_pass": unet.flops_executed / 1e12,
+                         "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0",
                          "how": "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"},
         }
         if a.epochs > 0 and info["timing"]["stage2"] > 0:

@@ -185,7 +185,9 @@ int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, 
 /* softmax(Q K^T * scale) V per head, flash style (torch SDPA / xformers via AttnProcessor2_0: attn1 on the VidToMe-merged
  * tokens, patch.py:170-176, and attn2 text cross-attention).  q/k/v/o point at head 0 of batch 0 with heads interleaved
  * in channels (head hh = channels [hh*d, (hh+1)*d)); ld* row strides and *bs batch strides in halves; d in {40, 80, 160}.
- * K/V batch = b / kv_div.  pack_kv = 0 reuses the K/V panels a previous call left in ws_kv (text K/V are constant per run).
+ * K/V batch = b / kv_div.  pack_kv bit 0: 0 reuses the K/V panels a previous call left in ws_kv (text K/V are constant per run); bit 1: the
+ * B samples are one half of an identical pair (the CFG halves before the first text cross-attention): the kernel variant is chosen as for 2 B
+ * samples, so the half alone gives the bits the full batch would have given.
  * ws_q (tcl_attention_q_bytes): packed Q panel + one int per 128-query block (head_dim 40, large launches: blocks whose speculative
  * softmax left the f16 range are flagged there and redone by the exact-maximum kernel of the same call); no initialisation needed. */
 size_t tcl_attention_q_bytes(int B, int H, int Tq, int d);

@@ -842,6 +842,8 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
                       hipStream_t st) {
     TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
     TCL_CHECK_ARG(d == 40 || d == 80 || d == 128 || d == 160);
+    const int pair = (pack_kv >> 1) & 1;            // bit 1: these B samples are one half of an identical pair -> pick the kernel variant as for 2 B
+    pack_kv &= 1;
     TCL_CHECK_ARG(!pack_kv || (k && v));
     const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
@@ -859,7 +861,7 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     // fills the chip several times over (750 TFLOP/s at T = 35.6k; the variants below reach 700 / 660 / 655 there); else one query block
     // per wave on a 2-slot ring at 4 blocks per CU (107 VGPRs: four waves per SIMD hide each other's softmax; 582 vs 557 TFLOP/s at T = 8.9k
     // for the 3-slot / 3-block variant).  d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
-    const bool qb2 = (long)B * H * (Tqp / 256) >= 1024;
+    const bool qb2 = (long)B * (pair ? 2 : 1) * H * (Tqp / 256) >= 1024;
     static const int var40 = getenv("TCL_FLASH40") ? atoi(getenv("TCL_FLASH40")) : 0;      // tuning hook: force a d = 40 variant (tools/ab)
     if (d == 40 && var40 == 4) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);

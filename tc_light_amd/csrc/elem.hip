@@ -390,7 +390,9 @@ int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, 
     TCL_LAUNCH_RET();
 }
 // workspace: per-block partials [B][nblk][64][2] f32, then the sums [B][64][2]
-static inline int gn_blocks_cap(int B) { int n = 2048 / B; return n < 4 ? 4 : (n > 256 ? 256 : n); }
+// The row partition of a sample depends on HW alone, never on the batch size: a sample's statistics are the same bits whether it is normalised alone
+// or in a batch of 600 (unet.py relies on it: the identical CFG halves are computed once).  (Until round 3 the cap shrank with B.)
+static inline int gn_blocks_cap(int B) { (void)B; return 256; }
 size_t tcl_groupnorm_workspace_bytes(int B, int C) { (void)C; return ((size_t)B * gn_blocks_cap(B) + B) * 64 * 2 * 4 + 256; }
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {

@@ -106,7 +106,7 @@ class Generator:
             idx = torch.tensor(frames, dtype=I32, device=self.dev)
             xin = torch.empty(2 * n, self.h, self.w, 8, dtype=H16, device=self.dev)
             L.tcl_pack_latents_f16(x, cc, idx, n, 0, 0, 0, self.h, self.w, xin, stream())
-            eps = self.unet.forward_many(xin, [len(c) for c in grp], self.h, self.w, t, text)
+            eps = self.unet.forward_many(xin, [len(c) for c in grp], self.h, self.w, t, text, cfg_pair=True)     # the pack kernel wrote both halves
             L.tcl_unpack_cfg_f16(eps, idx, n, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
 
     def _unet_yt(self, x_full, cc_full, items, nt_full, text_t, t):
@@ -119,7 +119,7 @@ class Generator:
             idx = torch.tensor(cols, dtype=I32, device=self.dev)
             xin = torch.empty(2 * n, nwin, self.h, 8, dtype=H16, device=self.dev)
             L.tcl_pack_latents_f16(x_full, cc_full, idx, n, 1, sl, nwin, self.h, self.w, xin, stream())
-            eps = self.unet.forward_many(xin, [len(ch) for ch in grp], nwin, self.h, t, text_t)
+            eps = self.unet.forward_many(xin, [len(ch) for ch in grp], nwin, self.h, t, text_t, cfg_pair=True)
             L.tcl_unpack_cfg_f16(eps, idx, n, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
                                  nkeep, nt_full, stream())
 

@@ -118,13 +118,13 @@ class Ops:
         self.L.tcl_ln_gemm_f16(x, gamma, beta, 1e-5, w, bias if bias is not None else 0, 0, c, M, N, K, K, K, c.shape[1], N, act, stream())
         return c
 
-    def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1):
+    def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1, pair=False):
         o = self.empty(B * Tq, Hh * d)
         wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
         if ws_kv is None:
             ws_kv = torch.empty(self.L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d), dtype=torch.uint8, device=self.dev)
         self.L.tcl_attention_f16(q, ldq, qbs, k if k is not None else 0, ldk, kbs, v if v is not None else 0, ldv, vbs, o, Hh * d,
-                                 Tq * Hh * d, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, pack_kv, wq, ws_kv, stream())
+                                 Tq * Hh * d, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, pack_kv | (2 if pair else 0), wq, ws_kv, stream())
         return o
 
 
@@ -191,7 +191,8 @@ class UNetEngine:
         w["conv_out"] = (_conv_w(sd["conv_out.weight"], d), _dev(sd["conv_out.bias"], d))
         self.w = w
         self._temb_cache = (None, None)
-        self.flops = 0.0          # algorithmic FLOPs executed (2*MACs), accumulated per forward for the roofline figure
+        self.flops = 0.0          # algorithmic FLOPs (2*MACs) of the reference's computation, accumulated per forward for the roofline figure
+        self.flops_executed = 0.0  # FLOPs that actually ran (== flops without the CFG-pair de-duplication)
         self.count_flops = False
 
     # ------------------------------------------------------------------ time embedding (once per timestep)
@@ -212,7 +213,8 @@ class UNetEngine:
         return proj
 
     # ------------------------------------------------------------------ blocks
-    def _resblock(self, p, x, B, Hh, Ww, tproj, skip=None, cskip=0):
+    def _resblock(self, p, x, B, Hh, Ww, tproj, skip=None, cskip=0, rep=1):
+        """rep: how many identical copies of these B samples the reference computes (FLOP accounting only)."""
         o, r = self.ops, self.res[p]
         HW = Hh * Ww
         cx = r["cin"] - cskip
@@ -226,16 +228,18 @@ class UNetEngine:
             else:
                 xc = x
             xs = o.gemm(xc, r["sc"][0], r["sc"][1])
-            self._fl(2.0 * B * HW * r["cin"] * r["cout"])
+            self._fl(rep * 2.0 * B * HW * r["cin"] * r["cout"], 2.0 * B * HW * r["cin"] * r["cout"])
         else:
             xs = x
         out, _, _ = o.conv3x3(hn2, B, Hh, Ww, r["cout"], r["c2"], r["b2"], resid=xs)
-        self._fl(2.0 * B * HW * 9 * (r["cin"] + r["cout"]) * r["cout"])
+        self._fl(rep * 2.0 * B * HW * 9 * (r["cin"] + r["cout"]) * r["cout"], 2.0 * B * HW * 9 * (r["cin"] + r["cout"]) * r["cout"])
         return out
 
-    def _fl(self, f):
+    def _fl(self, f, executed=None):
+        """f: algorithmic FLOPs of the reference's computation; executed: what ran here (less where the identical CFG halves are computed once)."""
         if self.count_flops:
             self.flops += f
+            self.flops_executed += f if executed is None else executed
 
     def _text_kv(self, blk, text):
         key = id(text)
@@ -266,26 +270,30 @@ class UNetEngine:
                 self._side = torch.cuda.Stream(device=self.dev, priority=-1 if prio == "high" else 0)
         return self._side
 
-    def _transformer(self, p, x, B, Fs, Hh, Ww, text):
+    def _transformer(self, p, x, B, Fs, Hh, Ww, text, pair_half=False):
         """x [B*N, C] with B = 2*sum(Fs) samples: the unconditional samples of all chunks (chunk order), then the conditional ones.
         Everything is batched over the chunks except attn1 of the merging levels, which runs chunk by chunk in the reference order
-        because each chunk's merge uses -- and updates -- this block's global-token bank (patch.py:59-82)."""
+        because each chunk's merge uses -- and updates -- this block's global-token bank (patch.py:59-82).
+        pair_half: x holds only the FIRST half of the B samples (see forward_many: the two classifier-free-guidance halves are identical up to
+        the first text cross-attention); proj_in, norm1, the VidToMe merge and attn1 run on that half, the result is duplicated before attn2."""
         o, L, blk = self.ops, self.L, self.tfm[p]
         C, N, Hd = blk["c"], Hh * Ww, sd15.HEADS
         d = C // Hd
-        M = B * N
+        ne = 1 if pair_half else 2                               # batch entries physically present through attn1
+        Bx = B // 2 * ne
+        M = Bx * N
         Ftot = B // 2
-        hn = o.groupnorm(x, C, *blk["gn"], B, N, 1e-6, False)
+        hn = o.groupnorm(x, C, *blk["gn"], Bx, N, 1e-6, False)
         h = o.gemm(hn, blk["pin"][0], blk["pin"][1])
-        self._fl(2.0 * M * C * C * 2)
+        self._fl(2.0 * B * N * C * C * 2, 2.0 * M * C * C * 2)
         # ---- attn1 over VidToMe-merged tokens (patch.py:161-179)
         merging = self.tome.merges(N) and os.environ.get("TCL_LN_METRIC", "1") != "0"
         n1, m1 = o.layernorm(h, *blk["ln"][0], M, C, metric=True) if merging else (o.layernorm(h, *blk["ln"][0], M, C), None)
         if not self.tome.merges(N):                             # downsample > max_downsample: per-frame attention
             qkv = o.gemm(n1, blk["qkv"])
-            a = o.attention(qkv, 3 * C, N * 3 * C, qkv[:, C:], 3 * C, N * 3 * C, qkv[:, 2 * C:], 3 * C, N * 3 * C, B, Hd, N, N, d)
+            a = o.attention(qkv, 3 * C, N * 3 * C, qkv[:, C:], 3 * C, N * 3 * C, qkv[:, 2 * C:], 3 * C, N * 3 * C, Bx, Hd, N, N, d, pair=pair_half)
             h = o.gemm(a, blk["o1"][0], blk["o1"][1], resid=h)
-            self._fl(2.0 * M * C * C * 4 + 4.0 * B * N * N * C)
+            self._fl(2.0 * B * N * C * C * 4 + 4.0 * B * N * N * C, 2.0 * M * C * C * 4 + 4.0 * Bx * N * N * C)
         else:
             off, xbs = 0, Ftot * N * C                          # a chunk's conditional rows sit xbs elements after its unconditional ones
             # The matching chain (bank order, dozens of small launches per chunk) runs on a side stream, ahead of the attention of the
@@ -301,7 +309,7 @@ class UNetEngine:
                 self.tome.select_chunk(ci)
                 with torch.cuda.stream(side):
                     merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
-                                                             metric=m1[off * N:] if m1 is not None else None)     # merged [2, T, C]
+                                                             metric=m1[off * N:] if m1 is not None else None, ne=ne)     # merged [ne, T, C]
                 if two:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -309,13 +317,16 @@ class UNetEngine:
                     merged.record_stream(main)                  # allocated on the side stream's pool, read on the main stream
                     if unm is not None:
                         unm.record_stream(main)
-                qkv = o.gemm(merged, blk["qkv"], M=2 * T)
-                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, 2, Hd, T, T, d)
-                y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=2 * T)
-                self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C)      # u_a(...) + x (patch.py:178-179)
-                self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C)
+                qkv = o.gemm(merged, blk["qkv"], M=ne * T)
+                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half)
+                y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=ne * T)
+                self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C, ne)  # u_a(...) + x (patch.py:178-179)
+                self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C, 2.0 * ne * T * C * C * 4 + 4.0 * ne * T * T * C)
                 off += F
             # (running the attention of alternate chunks on a second stream as well was measured: no further gain)
+        if pair_half:                                           # from here on the halves differ (text): both exist
+            h, x = torch.cat([h, h]), torch.cat([x, x])
+            M = B * N
         F = Ftot
         # ---- attn2: text cross-attention on the full tokens
         fuse_ln = C == 320 and os.environ.get("TCL_LN_GEMM", "1") != "0"      # norm2 / norm3 ride in the consumer's operand load (strip-resident Linear)
@@ -344,28 +355,36 @@ class UNetEngine:
     # orders -- data flow per chunk, bank order per block -- so inside a block only attn1 loops over the chunks; ResNet blocks,
     # norms, cross-attention, feed-forward and the non-merging levels see 8-31x more rows per GEMM and one launch instead of one
     # per chunk, and every weight matrix is streamed once per step.
-    def forward_many(self, x_in, Fs, Hh, Ww, t, text):
+    def forward_many(self, x_in, Fs, Hh, Ww, t, text, cfg_pair=False):
         """x_in [2*Ftot, Hh, Ww, 8] f16 (latents | concat_conds; Ftot = sum(Fs) samples in chunk order, twice: uncond, cond);
-        text [2, L, 768] f16 (uncond, cond).  Fs: chunk lengths in the reference's chunk order.  -> eps [2*Ftot, Hh, Ww, 4] f16."""
+        text [2, L, 768] f16 (uncond, cond).  Fs: chunk lengths in the reference's chunk order.  -> eps [2*Ftot, Hh, Ww, 4] f16.
+        cfg_pair: the caller GUARANTEES x_in[Ftot:] == x_in[:Ftot] (the classifier-free-guidance pair of generate.py:342-347: `torch.cat([latents] * 2)`
+        and the same concat_conds, written twice by tcl_pack_latents_f16).  The two halves then differ only through the text, which first enters in
+        attn2 of the first transformer block: conv_in, the first ResNet block and proj_in / norm1 / VidToMe merge / attn1 of that block run ONCE and
+        are duplicated -- the same bits as computing them twice (every kernel is deterministic and batch-row independent; with equal scores in both
+        entries the matching picks the first: `test_cfg_pair_dedup_bit_identical`).  TCL_CFG_DEDUP=0 computes both halves."""
         o, L, w = self.ops, self.L, self.w
         Ftot = sum(Fs)
         B = 2 * Ftot
+        half = bool(cfg_pair) and os.environ.get("TCL_CFG_DEDUP", "1") != "0"
+        Bh = Ftot if half else B                                # samples through the text-free prefix
         tproj = self._temb(t)
         self.tome.begin_step(Fs, (Hh, Ww))                      # every chunk's lock-step draws, in chunk order (patch.py:206-231)
-        col = o.empty(B * Hh * Ww, 128)
-        L.tcl_im2col3x3_small_f16(x_in, col, B, Hh, Ww, w["conv_in"][2], 128, stream())
+        col = o.empty(Bh * Hh * Ww, 128)
+        L.tcl_im2col3x3_small_f16(x_in, col, Bh, Hh, Ww, w["conv_in"][2], 128, stream())
         h = o.gemm(col, w["conv_in"][0], w["conv_in"][1])
         del col
-        self._fl(2.0 * B * Hh * Ww * 72 * 320)
+        self._fl(2.0 * B * Hh * Ww * 72 * 320, 2.0 * Bh * Hh * Ww * 72 * 320)
         sizes = [(Hh, Ww)]
-        skips = [(h, 320)]
+        skips = [(torch.cat([h, h]) if half else h, 320)]
         hh, ww, c = Hh, Ww, 320
         for i, co in enumerate(sd15.BLOCK_OUT):
             for j in range(2):
-                h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj)
+                first = half and i == 0 and j == 0
+                h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, Bh if first else B, hh, ww, tproj, rep=2 if first else 1)
                 c = co
                 if i < 3:
-                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text)
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text, pair_half=first)
                 skips.append((h, c))
             if i < 3:
                 h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)

@@ -102,13 +102,13 @@ class VidToMe:
 
     # Maps are int32 tensors: 1-D when the two batch entries share the matching (align_batch, merge.py:93-108), [2, n] when every entry has
     # its own (merge.py:109-118).  The three helpers below hide the difference from compute_merge.
-    def _gather(self, s1, bs1, mp, out, bso, n, C):
+    def _gather(self, s1, bs1, mp, out, bso, n, C, nb=2):
         L = self.L
         if mp is None or mp.dim() == 1:
-            L.tcl_gather_rows_f16(s1, bs1, 0, 0, mp if mp is not None else 0, out, bso, 2, n, C, stream())
+            L.tcl_gather_rows_f16(s1, bs1, 0, 0, mp if mp is not None else 0, out, bso, nb, n, C, stream())
         else:
             f1, fo = s1.reshape(-1), out.reshape(-1)
-            for b in range(2):
+            for b in range(nb):
                 L.tcl_gather_rows_f16(f1[b * bs1:], bs1, 0, 0, mp[b], fo[b * bso:], bso, 1, n, C, stream())
 
     def _compose(self, outer, inner, off, n):
@@ -119,26 +119,28 @@ class VidToMe:
             out = torch.empty(n, dtype=I32, device=self.dev)
             L.tcl_index_compose(outer, inner if inner is not None else 0, off, n, out, stream())
             return out
-        out = torch.empty(2, n, dtype=I32, device=self.dev)
-        for b in range(2):
+        nb = outer.shape[0] if outer.dim() == 2 else inner.shape[0]
+        out = torch.empty(nb, n, dtype=I32, device=self.dev)
+        for b in range(nb):
             L.tcl_index_compose(outer[b] if outer.dim() == 2 else outer, (inner[b] if inner.dim() == 2 else inner) if inner is not None else 0,
                                 off, n, out[b], stream())
         return out
 
-    def unmerge_add(self, h, bsh, y, T, unm, n, C):
+    def unmerge_add(self, h, bsh, y, T, unm, n, C, nb=2):
         """h[b][i] += y[b][unm[i]]: unmerge of attn1's output + residual (patch.py:178-179); unm None = identity."""
         L = self.L
         if unm is None or unm.dim() == 1:
-            L.tcl_gather_add_rows_f16(h, bsh, y, T * C, unm if unm is not None else 0, 2, n, C, stream())
+            L.tcl_gather_add_rows_f16(h, bsh, y, T * C, unm if unm is not None else 0, nb, n, C, stream())
         else:
             fh, fy = h.reshape(-1), y.reshape(-1)
-            for b in range(2):
+            for b in range(nb):
                 L.tcl_gather_add_rows_f16(fh[b * bsh:], bsh, fy[b * T * C:], T * C, unm[b], 1, n, C, stream())
 
-    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None, metric=None):
+    def _match(self, tokens, T, C, a_pos, na, b_pos, nb, ratio, tbs=None, affine=None, metric=None, ne=2):
         """tokens: two [T, C] slices tbs elements apart (default T*C: a contiguous [2, T, C]) -> (mrg [na-r+nb], unm [T]) int32 maps ([2, .]
         each without align_batch).  metric: the tokens' cosine-normalised rows in the same layout, when the producer already wrote them
-        (tcl_layernorm_metric_f16); otherwise they are normalised here.
+        (tcl_layernorm_metric_f16); otherwise they are normalised here.  ne: batch entries present (1: the unconditional / conditional pair is
+        known to be identical, see compute_merge).
         affine = (a_split, a_gap, b0): a_pos[i] = i if i < a_split else i + a_gap, b_pos[j] = b0 + j (true of the single-round VidToMe matches;
         lets the C = 320 matches take the strip-resident kernel, csrc/merge.hip::k_tome_match320 -- same maps, bit for bit)."""
         L = self.L
@@ -147,9 +149,9 @@ class VidToMe:
         if metric is not None:
             metric, mbs = metric.reshape(-1), (T * C if tbs is None else tbs)
         else:
-            metric = torch.empty(2 * T * C, dtype=H16, device=self.dev)
-            if tbs is None or tbs == T * C:
-                L.tcl_tome_normalize_f16(tokens, metric, 2 * T, C, stream())
+            metric = torch.empty(ne * T * C, dtype=H16, device=self.dev)
+            if ne == 1 or tbs is None or tbs == T * C:
+                L.tcl_tome_normalize_f16(tokens, metric, ne * T, C, stream())
             else:
                 flat = tokens.reshape(-1)
                 L.tcl_tome_normalize_f16(flat, metric, T, C, stream())
@@ -158,11 +160,11 @@ class VidToMe:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)        # zeroed once; every match leaves it zero again
         aligned = self.args["align_batch"]
-        shape = (na - r + nb,) if aligned else (2, na - r + nb)
+        shape = (na - r + nb,) if aligned else (ne, na - r + nb)
         mrg = torch.empty(shape, dtype=I32, device=self.dev)
-        unm = torch.empty((T,) if aligned else (2, T), dtype=I32, device=self.dev)
-        for b in range(1 if aligned else 2):                                    # aligned: ONE matching over both entries (scores concatenated along dst)
-            mt, mo, uo, Bt = (metric, mrg, unm, 2) if aligned else (metric[b * mbs:], mrg[b], unm[b], 1)
+        unm = torch.empty((T,) if aligned else (ne, T), dtype=I32, device=self.dev)
+        for b in range(1 if aligned else ne):                                   # aligned: ONE matching over both entries (scores concatenated along dst)
+            mt, mo, uo, Bt = (metric, mrg, unm, ne) if aligned else (metric[b * mbs:], mrg[b], unm[b], 1)
             if affine is not None:
                 L.tcl_tome_match_affine_f16(mt, mbs, Bt, C, a_pos, na, b_pos, nb, r, affine[0], affine[1], affine[2], mo, uo, self._ws, stream())
             else:
@@ -176,10 +178,13 @@ class VidToMe:
             return False
         return int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N))) <= self.args["max_downsample"]
 
-    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None, metric=None):
+    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None, metric=None, ne=2):
         """x: norm1 output of one chunk: the unconditional [F*N, C] rows at x, the conditional ones xbs elements further (default
         F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]); metric: x's cosine-normalised rows in the same layout if norm1 wrote them
-        (unet.py: tcl_layernorm_metric_f16), else None.  Returns None when this block is not merged, else
+        (unet.py: tcl_layernorm_metric_f16), else None.  ne = 1: x holds ONE entry because the caller knows the pair to be identical (the
+        classifier-free-guidance pair before the first text cross-attention, unet.py): with equal scores in both entries the matching picks
+        the first one (lowest concatenated dst index), i.e. exactly the single-entry matching -- same maps, merged tokens and bank [1, T, C].
+        Returns None when this block is not merged, else
         (merged [2,T,C], unm int32 [F*N] ([2, F*N] without align_batch) or None for identity, T)."""
         a = self.args
         if not self.merges(N):
@@ -195,9 +200,9 @@ class VidToMe:
             a_pos, b_pos = self._positions(cur, N, randf, unm_pre)
             single = unm_pre == 0 and cur <= a["target_stride"]                # dst = the N tokens of frame randf, src = the rest: affine
             mrg, unm, Tn = self._match(seq, T, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=sbs,
-                                       affine=(randf * N, N, randf * N) if single else None, metric=metric if seq is x else None)
-            nxt = torch.empty(2, Tn, C, dtype=H16, device=self.dev)
-            self._gather(seq, sbs, mrg, nxt, Tn * C, Tn, C)
+                                       affine=(randf * N, N, randf * N) if single else None, metric=metric if seq is x else None, ne=ne)
+            nxt = torch.empty(ne, Tn, C, dtype=H16, device=self.dev)
+            self._gather(seq, sbs, mrg, nxt, Tn * C, Tn, C, ne)
             if mrg1 is None:
                 mrg1, unm1 = mrg, unm
             else:
@@ -209,8 +214,8 @@ class VidToMe:
             local, TL = seq, T
         else:
             TL = N                                       # F == 1: nothing to merge locally; keep the [2, T, C] layout
-            if xbs == N * C:
-                local = x.reshape(-1)[:2 * N * C].view(2, N, C)
+            if xbs == N * C or ne == 1:
+                local = x.reshape(-1)[:ne * N * C].view(ne, N, C)
             else:
                 local = torch.empty(2, N, C, dtype=H16, device=self.dev)
                 L.tcl_gather_rows_f16(x, xbs, 0, 0, 0, local, N * C, 2, N, C, stream())
@@ -222,23 +227,24 @@ class VidToMe:
             if self.trace is not None:
                 self.trace.append(dict(name=name, F=F, unm=unm1, gather=mrg1, mrg1=mrg1, T=TL))
             return local, unm1, TL
+        assert bank.shape[0] == ne, "a block's bank was seeded with another number of batch entries (reset_global_tokens() between modes)"
         Tb = bank.shape[1]
         if self.coin > a["global_rand"]:                                        # patch.py:61-65: local tokens are src
             src_len, loff, boff = TL, 0, TL
         else:                                                                   # patch.py:66-70: bank tokens are src
             src_len, loff, boff = Tb, Tb, 0
         T = TL + Tb
-        cat = torch.empty(2, T, C, dtype=H16, device=self.dev)
-        L.tcl_gather_rows_f16(local, TL * C, 0, 0, 0, cat[:, loff:], T * C, 2, TL, C, stream())
-        L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, 2, Tb, C, stream())
+        cat = torch.empty(ne, T, C, dtype=H16, device=self.dev)
+        L.tcl_gather_rows_f16(local, TL * C, 0, 0, 0, cat[:, loff:], T * C, ne, TL, C, stream())
+        L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, ne, Tb, C, stream())
         mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
-                                     a["global_merge_ratio"], affine=(src_len, 0, src_len))
-        merged = torch.empty(2, Tm, C, dtype=H16, device=self.dev)
-        self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C)
+                                     a["global_merge_ratio"], affine=(src_len, 0, src_len), ne=ne)
+        merged = torch.empty(ne, Tm, C, dtype=H16, device=self.dev)
+        self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C, ne)
         unm = self._compose(unm2, unm1, loff, F * N)                            # 2s-unmerge then the randframe unmerges (func_warper(u_ls[::-1]))
         bmap = self._compose(mrg2, unm2[..., loff:].contiguous() if unm2.dim() == 2 else unm2[loff:], 0, TL)     # bank <- u(merged_tokens) (patch.py:80)
-        nb_ = torch.empty(2, TL, C, dtype=H16, device=self.dev)
-        self._gather(cat, T * C, bmap, nb_, TL * C, TL, C)
+        nb_ = torch.empty(ne, TL, C, dtype=H16, device=self.dev)
+        self._gather(cat, T * C, bmap, nb_, TL * C, TL, C, ne)
         self.banks[name] = nb_
         if self.trace is not None:
             self.trace.append(dict(name=name, F=F, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL, bmap=bmap))

@@ -180,3 +180,50 @@ def test_unet_small_odd_planes_vs_oracle(setup, Hh, Ww, Fs, Lt):
         got = torch.cat([eps[off:off + f], eps[F + off:F + off + f]])
         assert rel(got, ref) < 1e-2, (Hh, Ww, f, rel(got, ref))
         off += f
+
+
+@pytest.mark.parametrize("vidtome_on,align", [(True, True), (True, False), (False, True)])
+def test_cfg_pair_dedup_bit_identical(setup, monkeypatch, vidtome_on, align):
+    """The classifier-free-guidance halves of a UNet call are identical until the first text cross-attention (generate.py:342-347: `cat([latents] * 2)`,
+    the same concat_conds).  With cfg_pair=True the engine computes conv_in, the first ResNet block and proj_in / norm1 / VidToMe merge / attn1 of the
+    first transformer block ONCE and duplicates them; the noise prediction must be THE SAME BITS as computing both halves (TCL_CFG_DEDUP=0), and the
+    merge maps / banks of every block the same: every kernel on that prefix is deterministic and independent of the batch size (GroupNorm's row partition,
+    the attention kernel variant via the pair flag; GEMM K splits are 1 from 16 384 rows up -- the test is sized above that)."""
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vidtome import VidToMe
+    sd = setup[0]
+    tome = VidToMe("cuda", seed=5, enabled=vidtome_on, align_batch=align)
+    eng = UNetEngine(sd, "cuda", tome)
+    Hh, Ww, t = 32, 48, 601.0
+    Fs = [4, 4, 3, 1]                                     # 12 frames x 1536 tokens = 18 432 rows in the half batch
+    Ft = sum(Fs)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    xh = torch.randn(Ft, Hh, Ww, 8, device="cuda", generator=g).half()
+    x = torch.cat([xh, xh]).contiguous()
+    text = torch.randn(2, 77, 768, device="cuda", generator=g).half()
+    draws = [(1, 0.9), (3, 0.2), (0, 0.7), (0, 0.4)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TCL_CFG_DEDUP", mode)
+        outs = []
+        for step in range(2):                             # second call: every block's bank exists (bank-src and local-src merges)
+            tome.draws = list(draws) if vidtome_on else None
+            tome.trace = []
+            eng.count_flops, eng.flops, eng.flops_executed = True, 0.0, 0.0
+            eps = eng.forward_many(x, Fs, Hh, Ww, t, text, cfg_pair=True).clone()
+            outs.append((eps, [(d["name"], None if d["unm"] is None else d["unm"].clone()) for d in tome.trace], eng.flops, eng.flops_executed))
+        tome.reset_global_tokens(); tome.trace = None; tome.draws = None
+        res[mode] = outs
+    torch.cuda.synchronize()
+    for (e0, tr0, f0, x0), (e1, tr1, f1, x1) in zip(res["0"], res["1"]):
+        assert torch.isfinite(e1.float()).all()
+        assert torch.equal(e0, e1)
+        assert [a[0] for a in tr0] == [b[0] for b in tr1]
+        for (name, ua), (_, ub) in zip(tr0, tr1):
+            if ua is None or ub is None:
+                assert ua is None and ub is None, name
+            elif ua.shape == ub.shape:
+                assert torch.equal(ua, ub), name
+            else:                                         # per-sample maps of the de-duplicated block: one row instead of two identical ones
+                assert ua.dim() == 2 and torch.equal(ua[0], ua[1]) and torch.equal(ua[0], ub.reshape(-1)), name
+        assert f0 == f1 == x0 and x1 < 0.99 * f1           # the reference's FLOPs are counted either way; fewer were executed (2.5 % at this small size)

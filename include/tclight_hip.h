@@ -187,7 +187,8 @@ int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, 
  * in channels (head hh = channels [hh*d, (hh+1)*d)); ld* row strides and *bs batch strides in halves; d in {40, 80, 160}.
  * K/V batch = b / kv_div.  pack_kv bit 0: 0 reuses the K/V panels a previous call left in ws_kv (text K/V are constant per run); bit 1: the
  * B samples are one half of an identical pair (the CFG halves before the first text cross-attention): the kernel variant is chosen as for 2 B
- * samples, so the half alone gives the bits the full batch would have given.
+ * samples, so the half alone gives the bits the full batch would have given; bit 2: the panels in ws_q / ws_kv were already written by
+ * tcl_attention_pack_f16 (same arguments; e.g. on another stream, with the caller's event between the two): only the attention kernels run.
  * ws_q (tcl_attention_q_bytes): packed Q panel + one int per 128-query block (head_dim 40, large launches: blocks whose speculative
  * softmax left the f16 range are flagged there and redone by the exact-maximum kernel of the same call); no initialisation needed. */
 size_t tcl_attention_q_bytes(int B, int H, int Tq, int d);
@@ -195,6 +196,9 @@ size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d);
 int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
                       long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv,
                       hipStream_t st);
+/* The packing half of tcl_attention_f16 alone: Q panel (scaled) into ws_q and, with pack_kv bit 0, the K / V^T panels into ws_kv. */
+int tcl_attention_pack_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, int B, int H, int Tq,
+                           int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv, hipStream_t st);
 
 /* ---- VidToMe token merging (utils/VidToMe/vidtome/merge.py, patch.py:14-91); int32 maps live on the device ---- */
 /* metric / metric.norm(dim=-1) with f16 rounding of the norm and the quotient (merge.py:84, :386). */

@@ -837,26 +837,47 @@ size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
 // softmax(Q K^T * scale) V per head.  q/k/v point at head 0 of batch 0; row strides ld* and batch strides *bs in halves.
 // K/V batch index = b / kv_div (kv_div = F for the text cross-attention whose context repeats per frame, else 1).
 // pack_kv = 0 reuses the K/V panels already in ws_kv (same Bkv, H, Tk, d as the call that packed them).
+// The packing half of tcl_attention_f16 on its own (same panels, same workspace layout): Q (scaled) and, with pack_kv, K / V^T.  A caller that
+// runs it on another stream than the attention itself passes pack_kv bit 2 (and bit 0 = 0) to tcl_attention_f16 afterwards.
+static int attention_pack(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, int B, int H, int Tq,
+                          int Tk, int d, float scale, int kv_div, int pack_q, int pack_kv, void* ws_q, void* ws_kv, hipStream_t st) {
+    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
+    _Float16* Qp = (_Float16*)ws_q;
+    _Float16* Kp = (_Float16*)ws_kv;
+    _Float16* Vt = Kp + (((size_t)Bkv * H * Tkp * KS + 511) / 512) * 512;        // 1-KiB aligned
+    long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (KS / 8);
+    if (pack_q)
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,
+                           scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1);
+    if (pack_kv) {
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, KS, kc,
+                           d == 40 ? d : -1);
+        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV, d == 40 ? 1 : 0);
+    }
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+int tcl_attention_pack_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, int B, int H, int Tq,
+                           int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv, hipStream_t st) {
+    TCL_CHECK_ARG(q && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
+    TCL_CHECK_ARG(d == 40 || d == 80 || d == 128 || d == 160);
+    TCL_CHECK_ARG(!(pack_kv & 1) || (k && v));
+    return attention_pack(q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, H, Tq, Tk, d, scale, kv_div, 1, pack_kv & 1, ws_q, ws_kv, st);
+}
 int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, void* o, int ldo,
                       long obs, int B, int H, int Tq, int Tk, int d, float scale, int kv_div, int pack_kv, void* ws_q, void* ws_kv,
                       hipStream_t st) {
     TCL_CHECK_ARG(q && o && ws_q && ws_kv && B > 0 && H > 0 && Tq > 0 && Tk > 0 && kv_div > 0 && B % kv_div == 0);
     TCL_CHECK_ARG(d == 40 || d == 80 || d == 128 || d == 160);
     const int pair = (pack_kv >> 1) & 1;            // bit 1: these B samples are one half of an identical pair -> pick the kernel variant as for 2 B
+    const int prepacked = (pack_kv >> 2) & 1;       // bit 2: tcl_attention_pack_f16 already filled ws_q (and ws_kv): only the attention kernels run
     pack_kv &= 1;
     TCL_CHECK_ARG(!pack_kv || (k && v));
-    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
+    TCL_CHECK_ARG(!(prepacked && pack_kv));
+    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
     _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (((size_t)Bkv * H * Tkp * KS + 511) / 512) * 512;        // 1-KiB aligned
-    long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (KS / 8);
-    hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,
-                       scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1);
-    if (pack_kv) {
-        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, KS, kc,
-                           d == 40 ? d : -1);
-        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV, d == 40 ? 1 : 0);
-    }
+    if (attention_pack(q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, H, Tq, Tk, d, scale, kv_div, !prepacked, pack_kv, ws_q, ws_kv, st) != TCL_OK) return TCL_ELAUNCH;
     // d = 40: two query blocks per wave (shared K/V fragments), 4-slot ring and two tiles per barrier, 2 blocks per CU, when the grid still
     // fills the chip several times over (750 TFLOP/s at T = 35.6k; the variants below reach 700 / 660 / 655 there); else one query block
     // per wave on a 2-slot ring at 4 blocks per CU (107 VGPRs: four waves per SIMD hide each other's softmax; 582 vs 557 TFLOP/s at T = 8.9k

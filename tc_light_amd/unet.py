@@ -118,14 +118,26 @@ class Ops:
         self.L.tcl_ln_gemm_f16(x, gamma, beta, 1e-5, w, bias if bias is not None else 0, 0, c, M, N, K, K, K, c.shape[1], N, act, stream())
         return c
 
-    def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1, pair=False):
+    def attention(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, kv_div=1, ws_kv=None, pack_kv=1, pair=False, packed=None):
+        """packed: (ws_q, ws_kv) already filled by attention_pack (on whatever stream; the caller orders the two)."""
         o = self.empty(B * Tq, Hh * d)
-        wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
-        if ws_kv is None:
-            ws_kv = torch.empty(self.L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d), dtype=torch.uint8, device=self.dev)
+        if packed is not None:
+            wq, ws_kv, flags = packed[0], packed[1], 4
+        else:
+            wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
+            if ws_kv is None:
+                ws_kv = torch.empty(self.L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d), dtype=torch.uint8, device=self.dev)
+            flags = pack_kv
         self.L.tcl_attention_f16(q, ldq, qbs, k if k is not None else 0, ldk, kbs, v if v is not None else 0, ldv, vbs, o, Hh * d,
-                                 Tq * Hh * d, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, pack_kv | (2 if pair else 0), wq, ws_kv, stream())
+                                 Tq * Hh * d, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, flags | (2 if pair else 0), wq, ws_kv, stream())
         return o
+
+    def attention_pack(self, q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d):
+        """Q / K / V^T panels of one attention call, written on the current stream -> (ws_q, ws_kv) for attention(..., packed=)."""
+        wq = torch.empty(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
+        wkv = torch.empty(self.L.tcl_attention_kv_bytes(B, Hh, Tk, d), dtype=torch.uint8, device=self.dev)
+        self.L.tcl_attention_pack_f16(q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, Hh, Tq, Tk, d, d ** -0.5, 1, 1, wq, wkv, stream())
+        return wq, wkv
 
 
 class UNetEngine:
@@ -305,20 +317,30 @@ class UNetEngine:
             side = self._side_stream() if two else main
             if two:
                 side.wait_stream(main)                          # n1 is ready
+            # The chunk's QKV projection rides on the side stream too (TCL_QKV_SIDE): it only depends on the merge, and the main stream is the
+            # critical path of the pass (97 % busy) while the side stream has slack.
+            qkv_side = two and os.environ.get("TCL_QKV_SIDE", "1") != "0"
             for ci, F in enumerate(Fs):
                 self.tome.select_chunk(ci)
                 with torch.cuda.stream(side):
                     merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
                                                              metric=m1[off * N:] if m1 is not None else None, ne=ne)     # merged [ne, T, C]
+                    packed = None
+                    if qkv_side:
+                        qkv = o.gemm(merged, blk["qkv"], M=ne * T)
+                        packed = o.attention_pack(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d)
                 if two:
                     ev = torch.cuda.Event()
                     ev.record(side)
                     main.wait_event(ev)
-                    merged.record_stream(main)                  # allocated on the side stream's pool, read on the main stream
+                    for tns in ((qkv,) + packed) if qkv_side else (merged,):       # allocated on the side stream's pool, read on the main stream
+                        tns.record_stream(main)
                     if unm is not None:
                         unm.record_stream(main)
-                qkv = o.gemm(merged, blk["qkv"], M=ne * T)
-                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half)
+                if not qkv_side:
+                    qkv = o.gemm(merged, blk["qkv"], M=ne * T)
+                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half,
+                                packed=packed)
                 y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=ne * T)
                 self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C, ne)  # u_a(...) + x (patch.py:178-179)
                 self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C, 2.0 * ne * T * C * C * 4 + 4.0 * ne * T * T * C)

@@ -317,9 +317,10 @@ class UNetEngine:
             side = self._side_stream() if two else main
             if two:
                 side.wait_stream(main)                          # n1 is ready
-            # The chunk's QKV projection rides on the side stream too (TCL_QKV_SIDE): it only depends on the merge, and the main stream is the
-            # critical path of the pass (97 % busy) while the side stream has slack.
-            qkv_side = two and os.environ.get("TCL_QKV_SIDE", "1") != "0"
+            # TCL_QKV_SIDE=1: the chunk's QKV projection and panel packing ride on the side stream too (they only depend on the merge, and the main
+            # stream is the critical path of the pass).  Measured: -0.7 % denoise time on a same-box A/B, +0.4 % frames/s on the full clip, but the
+            # flash kernel's in-pass rate drops 3.5 % (more work shares the matrix pipes with it): off by default.
+            qkv_side = two and os.environ.get("TCL_QKV_SIDE", "0") != "0"
             for ci, F in enumerate(Fs):
                 self.tome.select_chunk(ci)
                 with torch.cuda.stream(side):

@@ -147,6 +147,16 @@ def test_attention(L, d, B, Tq, Tk, kv_div):
     o2 = torch.zeros_like(o)
     L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o2, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 0, wq, wkv, st())
     assert torch.equal(o, o2)
+    # the packing half on its own (tcl_attention_pack_f16, possibly on another stream) + the attention kernels alone (pack_kv bit 2): same bits
+    wq3, wkv3 = ws_bytes(L.tcl_attention_q_bytes(B, Hh, Tq, d)), ws_bytes(L.tcl_attention_kv_bytes(B // kv_div, Hh, Tk, d))
+    o3 = torch.zeros_like(o)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L.tcl_attention_pack_f16(q, C, Tq * C, k, C, Tk * C, v, C, Tk * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 1, wq3, wkv3, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o3, C, Tq * C, B, Hh, Tq, Tk, d, d ** -0.5, kv_div, 4, wq3, wkv3, st())
+    assert torch.equal(o, o3)
 
 
 def test_pack_unpack_adain(L):

@@ -1,6 +1,7 @@
 """bench.py -- end-to-end relight throughput of the MI355X TC-Light engine on BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torch.distributed.run -- started by the driver,
+                                                          or by bench.py itself when it finds no WORLD_SIZE in its environment)
 
 Workload = the configuration BASELINE.json's metric is quoted on: 300 frames 1280x720, 20 denoising steps, --multi_axis (alpha_t 0.01),
 VidToMe 0.6/0.5, stage 1 35 epochs + stage 2 70 epochs -- the region the reference times (generate.py:578-611) minus optical-flow
@@ -44,8 +45,13 @@ def parse():
     ap.add_argument("--epochs_exposure", type=int, default=35)
     ap.add_argument("--epochs", type=int, default=70)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_full", action="store_true", help="the FULL SURVEY 8(d) CPU sample (merged 4-frame xy chunk + yt chunk through the oracle "
-                    "UNet, 3 iterations of each optimiser stage at batch 16): minutes of host time instead of the default ~30 s sample")
+    ap.add_argument("--cpu_bounded", action="store_true", help="a ~30 s CPU sample (single-frame un-merged UNet calls, one optimiser iteration on 4 frames) "
+                    "instead of the default: SURVEY 8(d)'s sample as written (merged 4-frame xy chunk + yt chunk through the oracle UNet, 3 iterations "
+                    "of each optimiser stage at batch 16; ~4 minutes of host time)")
+    ap.add_argument("--cpu_full", action="store_true", help="(default since round 4; kept so that older command lines still parse)")
+    ap.add_argument("--profile_steps", type=int, default=5, help="denoising steps of the untimed PROFILED pass behind the timed one (HIP events around every "
+                    "flash / GEMM / match launch -> roofline, roofline_gemm, roofline_match); 0 = no profiled pass")
+    ap.add_argument("--profile_in_pass", action="store_true", help="round-3 behaviour: record the flash events inside the timed pass instead")
     ap.add_argument("--no_extras", action="store_true", help="skip the figures reported beside the metric (configs[1] pass, flow estimation / matting)")
     ap.add_argument("--exclusive", action="store_true", help="one extra untimed pass with the matching chain on the main stream (flash kernel alone on the GPU)")
     ap.add_argument("--no_multi_axis", action="store_true")
@@ -172,13 +178,13 @@ def cpu_baseline(sd_unet, H, W, n_frames, flops_path1, cfg, full=False):
     total = flops_path1 / cpu_rate + per_epoch * (cfg["epochs_exposure"] * t_it1 + cfg["epochs"] * t_it2)
     return dict(value=n_frames / total, unit="frames/s", cores=cores, kind="port", host_cpu=_cpu_model(), host_logical_cpus=ncpu,
                 threads_tried={str(k): round(v, 3) for k, v in tried.items()},
-                sample=f"{'FULL SURVEY 8(d) sample' if full else 'bounded sample'}: oracle UNet forward at full latent resolution: xy plane {w}x{h} on "
+                sample=f"{'FULL SURVEY 8(d) sample' if full else 'bounded sample (--cpu_bounded)'}: oracle UNet forward at full latent resolution: xy plane {w}x{h} on "
                        f"{F} frame(s){' with VidToMe merging' if full else ''} ({meas[0][0] / 1e12:.2f} TFLOP unmerged-equivalent in {meas[0][1]:.1f} s) + yt "
                        f"plane {h}x{min(64, n_frames)} on {F} column(s) ({meas[1][0] / 1e12:.2f} TFLOP in {meas[1][1]:.1f} s) = {cpu_rate / 1e12:.3f} TFLOP/s on {cores} "
                        f"threads (probe: {tried}); oracle stage-1 / stage-2: {its} iteration(s) on a {bsz}-frame batch at {W}x{H} ({t_it1:.1f} / {t_it2:.1f} s per "
                        f"{cfg['batch_size']}-frame iteration); extrapolated: {flops_path1 / 1e15:.2f} PFLOP of UNet work / CPU rate + "
-                       f"{per_epoch * cfg['epochs_exposure']} + {per_epoch * cfg['epochs']} optimiser iterations (VAE left out).  Config 1 in full on the oracle: "
-                       f"tests/test_gpu_e2e.py prints it (129 s for denoise + VAE on 64 threads in round 2)")
+                       f"{per_epoch * cfg['epochs_exposure']} + {per_epoch * cfg['epochs']} optimiser iterations (VAE left out)",
+                sample_kind="survey_8d_full" if full else "bounded")
 
 
 def unet_flops_unmerged(B, h, w, L):
@@ -258,24 +264,107 @@ def measured_traffic():
         return None, None
 
 
+def path2_traffic():
+    """HBM bytes per stage-2 iteration of THIS workload (300 x 1280 x 720, the bench's own codebook) from the committed PMC passes
+    (profiles/r*_path2_traffic.json <- tools/collect_path2_traffic.sh; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md).  Counters cannot be
+    read from inside the timed process: the newest committed measurement is reported with the file it came from."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_path2_traffic.json")))
+    if not fs:
+        return None, None
+    try:
+        return json.load(open(fs[-1]))["hbm_bytes_per_stage2_iteration"], os.path.basename(fs[-1])
+    except Exception:
+        return None, None
+
+
+def config3_pass(unet, vae, base, conds, conds_t, d, dev):
+    """BASELINE.json configs[3] as ONE pass (configs/examples/tclight_bkgd_robotwin.yaml): 60 frames 960x720, foreground / background mode -- alpha
+    from the BriaRMBG engine (seeded weights), `alpha*fg + (1-alpha)*bg` against a constant background (generate.py:147-167) -- VidToMe ratios
+    local 0.9 / global 0.8, 20 steps, multi-axis, 35 + 70 epochs.  Run twice; the second pass is timed (the first fills the tile table for its
+    merged lengths when the committed table lacks them)."""
+    from tc_light_amd import rmbg as RM
+    from tc_light_amd.generate import Generator
+    n, H, W = 60, 720, 960
+    f, fl, m, i, k = synth_inputs(n, H, W, 0, n, dev)
+    bg = torch.full((1, 3, H, W), 0.35, device=dev)
+    rm = RM.RMBGEngine(RM.random_state_dict(1), dev)
+    cfg = dict(base, n_timesteps=BASE_STEPS, epochs_exposure=35, epochs=70, local_merge_ratio=0.9, global_merge_ratio=0.8)
+    g = Generator(unet, vae, cfg, dist=d, rmbg=rm)
+    before = int(lib_size())
+    try:
+        g(f, conds, conds_t, fl, m, i, n_total=n, k=k, background=bg)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        out, inf = g(f, conds, conds_t, fl, m, i, n_total=n, k=k, background=bg)
+        torch.cuda.synchronize(); t1 = time.perf_counter() - t1
+        ok = bool(torch.isfinite(out).all())
+    finally:
+        # the engine's VidToMe arguments are per Generator (generate.py:__init__): put the metric's ratios back for whatever runs next
+        unet.tome.args.update(local_merge_ratio=0.6, global_merge_ratio=0.5)
+    return {"workload": "60 frames 960x720, 20 steps, multi_axis, VidToMe 0.9/0.8, RMBG alpha blend on a constant background, 35+70 epochs "
+                        "(BASELINE.json configs[3], tclight_bkgd_robotwin.yaml)", "frames_per_s": n / t1, "finite": ok,
+            "phase_seconds": {kk: round(v, 3) for kk, v in inf["timing"].items()}, "gemm_shapes_not_in_committed_table": int(lib_size()) - before}
+
+
+def lib_size():
+    from tc_light_amd.lib import lib
+    return lib().tcl_gemm_tune_size()
+
+
+def _free_port():
+    import socket
+    so = socket.socket(); so.bind(("127.0.0.1", 0)); p = so.getsockname()[1]; so.close()
+    return p
+
+
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N ranks of this same command under torch.distributed.run (the
+    launcher the driver itself uses for N > 1) on this node and hand back its exit status -- a plain `--gpus 8` never silently runs one rank.
+    TCL_DIST_BACKEND=gloo lets the ranks share GPUs (dry run of the whole N > 1 path on a 1-GPU box; RCCL refuses two ranks on one device)."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("TCL_DIST_BACKEND", "nccl")
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (tc_light_amd has no CPU fallback)")
+    if ndev < n and backend == "nccl":
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {ndev} GPU(s) and RCCL needs one device per rank.  Run with --gpus {ndev}, or set "
+                         f"TCL_DIST_BACKEND=gloo for a dry run in which the {n} ranks share the {ndev} device(s).")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks ({backend}): {' '.join(cmd[1:7])} ...", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_as_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (tc_light_amd has no CPU fallback)")
-    local = local % torch.cuda.device_count()          # (lets a 2-rank gloo dry run share one GPU; one rank per GPU otherwise)
+    backend = os.environ.get("TCL_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s): RCCL needs one device per rank (TCL_DIST_BACKEND=gloo shares devices)")
+    local = local % ndev                               # (a gloo dry run may put several ranks on one GPU; one rank per GPU otherwise)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("TCL_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        to = datetime.timedelta(seconds=int(os.environ.get("TCL_DIST_TIMEOUT", "900")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=to)
+            else:
+                dist.init_process_group(backend, timeout=to)
+        except Exception as e:
+            raise SystemExit(f"bench.py rank {rank}/{world}: init_process_group({backend}) failed: {e!r} -- check MASTER_ADDR/MASTER_PORT "
+                             f"({os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}) and that all {world} ranks started")
     if a.gpus != world:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
 
@@ -289,7 +378,7 @@ def main():
     from tc_light_amd.unet import UNetEngine
     from tc_light_amd.vae import VAEEngine
     from tc_light_amd.vidtome import VidToMe
-    d = Dist(rank, world)
+    d = Dist(rank, world, timed=world > 1)
     d.barrier()
 
     n_total, H, W = a.frames, a.height, a.width
@@ -312,33 +401,52 @@ def main():
     conds_t = torch.from_numpy(g.standard_normal((2, 77, 768)).astype(np.float32)).to(dev).half()
 
     def one_pass(generator, profile=False):
+        """profile: HIP events around every head_dim-40 flash launch, every GEMM / implicit-conv call and every VidToMe match call of this pass
+        (in-library, on the launch streams) -> ((flash ms, FLOP, launches, largest shape), (gemm ms, FLOP, calls), (match ms, FLOP, calls))."""
         if profile:
             lib().tcl_flash_profile_begin(40)
-            unet.flops, unet.flops_executed, unet.count_flops = 0.0, 0.0, True
+            lib().tcl_prof_begin(3)
+        unet.flops, unet.flops_executed, unet.count_flops = 0.0, 0.0, True
         out, info = generator(frames, conds, conds_t, flows, masks, inv, n_total=n_total, k=K)
+        unet.count_flops = False
         prof = None
         if profile:
             ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
             lib().tcl_flash_profile_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
             shp = (ctypes.c_int * 4)()
             lib().tcl_flash_profile_shape(shp)
-            prof = (ms.value, fl.value, cnt.value, tuple(shp))
-            unet.count_flops = False
+            prof = [(ms.value, fl.value, cnt.value, tuple(shp))]
+            for cls in (0, 1):
+                lib().tcl_prof_end(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+                prof.append((ms.value, fl.value, cnt.value))
         return out, info, prof
 
     if a.warmup > 0:       # untimed: W denoising steps + one epoch of each optimiser stage on the same inputs
         one_pass(Generator(unet, vae, dict(base, n_timesteps=a.warmup, epochs_exposure=1, epochs=1), dist=d))
+    d.reset_stats()
     d.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     info = prof = None
     for s in range(passes):
-        out, info, p = one_pass(gen, profile=(s == 0))
+        out, info, p = one_pass(gen, profile=(a.profile_in_pass and s == 0))
         prof = prof or p
     d.barrier(); torch.cuda.synchronize()
     dt = d.max_float(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all(), "non-finite output"
+    flops_pass, flops_exec = unet.flops, unet.flops_executed
+    coll = {k: dict(v) for k, v in d.stats.items()}
     if a.save_gemm_table and rank == 0:
         lib().tcl_gemm_tune_save(a.save_gemm_table)
+
+    # The profiled pass: the same clip, same shapes, `--profile_steps` denoising steps and one epoch of each stage, UNTIMED, with HIP events around
+    # every launch of the three matrix-pipe consumers (round 3 recorded the flash events inside the timed pass: 59k event records in the
+    # measured region).  Every rank runs it (the collectives need all of them); rank 0's numbers are reported.
+    prof_how = "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"
+    if not a.profile_in_pass and a.profile_steps > 0:
+        _, _, prof = one_pass(Generator(unet, vae, dict(base, n_timesteps=a.profile_steps, epochs_exposure=1, epochs=1), dist=d), profile=True)
+        prof_how = (f"HIP events around every launch on the launch stream (in-library), rank 0, in an UNTIMED profiled pass run right behind the timed one: "
+                    f"same clip and shapes, {a.profile_steps} denoising steps, matching chain on its side stream as in the timed pass")
+    d.barrier(); torch.cuda.synchronize()
 
     # In the timed region the VidToMe matching chain runs on a second stream beside the attention kernels (DESIGN 4.1), so the launch
     # durations above are those of a kernel SHARING the GPU.  --exclusive: one extra untimed pass with the chain back on the main stream.
@@ -351,8 +459,16 @@ def main():
             del os.environ["TCL_TOME_STREAM"]
         torch.cuda.synchronize()
 
+    per_rank = None
+    if world > 1:
+        import torch.distributed as dist
+        mine = {"timing": info["timing"], "collectives": coll, "frames": hi - lo, "max_memory_allocated_MiB": round(info["max_memory_allocated"])}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        per_rank = allr
+
     if rank == 0:
-        ms, fl, cnt = prof[:3]
+        ms, fl, cnt = prof[0][:3] if prof else (0.0, 0.0, 0)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         is_base = (n_total, H, W, n_steps, a.epochs_exposure, a.epochs, a.no_multi_axis) == (300, 720, 1280, BASE_STEPS, 35, 70, False)
         traffic, traffic_src = measured_traffic()
@@ -368,7 +484,9 @@ def main():
                        "step": "one denoising step of the end-to-end pass; the timed region is the whole pass (VAE encode/decode and both optimiser stages included)",
                        "frames_total": n_total, "passes_timed": passes, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
                        "parallelism": (f"frames sharded x{world} (38/37 per rank at 300), yt-plane all-gather + all-reduce per step, decoded frames all-gathered, "
-                                       f"stage 1/2 replicated on every rank (no collective; bit-reproducible)") if world > 1 else "single GPU",
+                                       f"stage 1/2 replicated on every rank (no collective; bit-reproducible); backend {backend}"
+                                       + (" -- ranks SHARE GPUs (dry run of the N > 1 path, not a scaling measurement)" if ndev < world else ""))
+                                      if world > 1 else "single GPU",
                        "gemm_tile_table_entries_loaded": table_entries},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
             "pass_seconds": dt / passes, "input_synthesis_seconds": round(t_setup, 1),
@@ -376,11 +494,38 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_flash<40,...> (head_dim 40 attention: self-attention over VidToMe-merged tokens + text cross-attention)",
                          "achieved": ach, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F16_DENSE_PEAK_TFLOPS,
                          "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": unet.flops / 1e12,
-                         "unet_executed_tflop_per_pass": unet.flops_executed / 1e12,
-                         "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0",
-                         "how": "HIP events around every launch on the launch stream, timed pass 0, rank 0 (tcl_flash_profile_*)"},
+                         "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": flops_pass / 1e12,
+                         "unet_executed_tflop_per_pass": flops_exec / 1e12,
+                         "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0", "how": prof_how},
         }
+        if prof and len(prof) > 2:
+            # the other two matrix-pipe consumers of the denoise loop, same profiled pass, same units (the 48 PFLOP of VidToMe score
+            # GEMMs were in no roofline figure; the GEMM family had none of its own)
+            for key, (pms, pfl, pcnt), what in (
+                    ("roofline_gemm", prof[1], "GEMM / implicit-conv3x3 family: every tcl_gemm_f16 / tcl_conv3x3_f16 / tcl_ln_gemm_f16 call of the UNet + VAE "
+                                               "(k_gemm8p / k_gemm8s / k_gemm_dma / k_lin_strip / k_gemm), 2 M N K FLOP per call"),
+                    ("roofline_match", prof[2], "VidToMe matching: every tcl_tome_match*_f16 call (score GEMM k_tome_match320 / k_tome_match + threshold + "
+                                                "map kernels inside the bracket), 2 n_src n_dst C B FLOP per call (merge.py:84-108, :389-421)")):
+                pa = pfl / (pms * 1e-3) / 1e12 if pms > 0 else 0.0
+                res[key] = {"bound": "mfma", "kernel": what, "achieved": pa, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": pa / MFMA_F16_DENSE_PEAK_TFLOPS, "calls": pcnt, "kernel_seconds": pms * 1e-3, "algorithmic_tflop_in_calls": pfl / 1e12,
+                            "traffic": None, "how": prof_how}
+        if per_rank:
+            ph = sorted(per_rank[0]["timing"])
+            names = sorted({k for r in per_rank for k in r["collectives"]})
+            res["per_rank"] = {
+                "frames": [r["frames"] for r in per_rank],
+                "phase_seconds_min_max": {k: [round(min(r["timing"][k] for r in per_rank), 3), round(max(r["timing"][k] for r in per_rank), 3)] for k in ph},
+                "collectives": {k: {"calls": max(r["collectives"].get(k, {}).get("calls", 0) for r in per_rank),
+                                    "seconds_min_max": [round(min(r["collectives"].get(k, {}).get("seconds", 0.0) for r in per_rank), 4),
+                                                        round(max(r["collectives"].get(k, {}).get("seconds", 0.0) for r in per_rank), 4)],
+                                    "bytes_per_rank": max(r["collectives"].get(k, {}).get("bytes", 0) for r in per_rank)} for k in names},
+                "seconds_in_collectives_max": round(max(sum(c["seconds"] for c in r["collectives"].values()) for r in per_rank), 4),
+                "collective_bytes_per_denoise_step_per_rank": int(sum(per_rank[0]["collectives"].get(k, {}).get("bytes", 0)
+                                                                      for k in ("all_gather_frames", "all_reduce_yt_noise")) / max(passes * n_steps, 1)),
+                "max_memory_allocated_MiB": [r["max_memory_allocated_MiB"] for r in per_rank],
+                "note": "seconds in a collective = host clock between device synchronises around the call on that rank: the wait for the slowest rank "
+                        "is inside it (min over ranks ~ the transfer itself, max ~ transfer + load imbalance)"}
         if a.epochs > 0 and info["timing"]["stage2"] > 0:
             # Path 2's dominant kernel group: one stage-2 iteration (gather, losses, codebook gradient, dense Adam).  Algorithmic HBM bytes per
             # iteration: (56 + 48 + 24) b P for the mini-batch + 84 K for the dense Adam stream; time = the stage's wall clock inside
@@ -389,34 +534,37 @@ def main():
             by2 = (56 + 48 + 24) * cfg["batch_size"] * H * W + 84 * int(K)
             t_it = info["timing"]["stage2"] / it2
             it1 = a.epochs_exposure * (-(-n_total // cfg["batch_size"]))
+            tr2, tr2_src = path2_traffic()
             res["roofline_path2"] = {"bound": "hbm", "kernel": "stage-2 iteration (unique-tensor optimisation: codebook gather, MS-SSIM / TV / flow losses + "
                                      "gradients, frame-ordered codebook gradient, Adam over all K rows)", "achieved": by2 / t_it / 1e9, "peak": 8000.0,
-                                     "unit": "GB/s", "frac": by2 / t_it / 8e12, "traffic": None, "iterations": it2, "ms_per_iteration": t_it * 1e3,
+                                     "unit": "GB/s", "frac": by2 / t_it / 8e12, "traffic": tr2, "traffic_source": tr2_src,
+                                     "frac_traffic": (tr2 / t_it / 8e12) if tr2 else None,
+                                     "iterations": it2, "ms_per_iteration": t_it * 1e3,
                                      "algorithmic_bytes_per_iteration": by2,
                                      "adam_schedule": ("lazy" if int(K) > 3 * 2 * cfg["batch_size"] * H * W else "dense"),
                                      "note": "`achieved` credits the reference algorithm's bytes (84 B per codebook row and iteration for its dense Adam); "
                                              "with the lazy schedule (bit-identical results) rows outside the mini-batch are not moved, so this is an effective "
-                                             "rate, not HBM traffic",
+                                             "rate, not HBM traffic: `traffic` = HBM bytes per iteration from the committed PMC passes of this workload and "
+                                             "`frac_traffic` = traffic / this run's iteration time / 8 TB/s is the HBM utilisation",
                                      "stage1": {"ms_per_iteration": info["timing"]["stage1"] / max(it1, 1) * 1e3, "iterations": it1,
                                                 "achieved": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 1e9,
                                                 "frac": 2 * 60 * cfg["batch_size"] * H * W / (info["timing"]["stage1"] / max(it1, 1)) / 8e12},
                                      "how": "phase wall clock of the timed pass / iterations; bit-reproducible run to run (fixed-point accumulators)"}
-        if len(prof) > 3 and prof[3][2] > 0:
-            res["roofline"]["alone"] = flash_alone(prof[3], dev)
-        if prof_ex and prof_ex[0] > 0:
-            ax = prof_ex[1] / (prof_ex[0] * 1e-3) / 1e12
-            res["roofline"]["exclusive"] = {"achieved": ax, "frac": ax / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": prof_ex[0] / max(prof_ex[2], 1),
+        if prof and prof[0][3][2] > 0:
+            res["roofline"]["alone"] = flash_alone(prof[0][3], dev)
+        if prof_ex and prof_ex[0][0] > 0:
+            ax = prof_ex[0][1] / (prof_ex[0][0] * 1e-3) / 1e12
+            res["roofline"]["exclusive"] = {"achieved": ax, "frac": ax / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": prof_ex[0][0] / max(prof_ex[0][2], 1),
                                             "how": "same launches in one extra untimed pass with the matching chain on the main stream (TCL_TOME_STREAM=0)"}
-        flops_pass = unet.flops
         if world == 1 and not a.no_extras:
             del out
             try:                                               # the SURVEY 8(f) rows, measured beside the metric (never part of `value`)
                 res["producers"] = producer_timings(frames, dev)
             except Exception as e:
                 res["producers"] = {"error": repr(e)}
+            del frames, flows, masks, inv
+            torch.cuda.empty_cache()
             try:                                               # BASELINE.json configs[1] (round 1's bench workload), kept as an extra key
-                del frames, flows, masks, inv
-                torch.cuda.empty_cache()
                 f2, fl2, m2, i2, k2 = synth_inputs(30, 720, 960, 0, 30, dev)
                 g2 = Generator(unet, vae, dict(base, n_timesteps=BASE_STEPS, epochs_exposure=35, epochs=70), dist=d)
                 g2(f2, conds, conds_t, fl2, m2, i2, n_total=30, k=k2)                  # (its shapes' tiles: table or tuned here)
@@ -425,11 +573,16 @@ def main():
                 torch.cuda.synchronize(); t1 = time.perf_counter() - t1
                 res["configs1"] = {"workload": "30 frames 960x720, 20 steps, multi_axis, 35+70 epochs (BASELINE.json configs[1])",
                                    "frames_per_s": 30 / t1, "phase_seconds": {k: round(v, 3) for k, v in inf2["timing"].items()}}
+                del f2, fl2, m2, i2, g2
             except Exception as e:
                 res["configs1"] = {"error": repr(e)}
+            try:                                               # BASELINE.json configs[3]: foreground / background mode, VidToMe 0.9 / 0.8
+                res["configs3"] = config3_pass(unet, vae, base, conds, conds_t, d, dev)
+            except Exception as e:
+                res["configs3"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, flops_pass, cfg, full=a.cpu_full)
+                res["cpu_baseline"] = cpu_baseline(sd_unet, H, W, n_total, flops_pass, cfg, full=not a.cpu_bounded)
             except Exception as e:  # the baseline must never sink the measurement
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

@@ -244,6 +244,12 @@ int tcl_flowid(const float* frames, const float* fwd_flows, const float* masks, 
 int tcl_flash_profile_begin(int dfilter);
 int tcl_flash_profile_end(double* total_ms, double* total_flops, long* launches);
 int tcl_flash_profile_shape(int* shape4);        /* (B, H, Tq, Tk) of the largest launch profiled since _begin */
+/* The same for the other two matrix-pipe consumers of path 1 (bench.py `roofline_gemm`, `roofline_match`): mask bit 0 = every
+ * tcl_gemm_f16 / tcl_conv3x3_f16 / tcl_ln_gemm_f16 call (work = 2 M N K FLOP, the conv and Linear layers of SURVEY A9), bit 1 = every
+ * tcl_tome_match*_f16 call (work = 2 n_src n_dst C Bt FLOP, the score GEMM of merge.py:84-108 / :389-421; the call's threshold and
+ * map kernels are inside the bracket).  _end(cls = bit index) synchronises that class's events and switches it off. */
+int tcl_prof_begin(int mask);
+int tcl_prof_end(int cls, double* total_ms, double* total_work, long* launches);
 
 /* ---- MemFlowNet correlation lookup (utils/evaluation/memflow/core/Networks/MemFlowNet/corr.py:74-120 CorrBlock,
  * computed on demand like the reference's unused alt_cuda_corr extension -- the all-pairs volume never exists).  f32, NHWC feature maps.

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <unordered_map>
 #include "gemm_conv.h"
+#include "prof.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -509,7 +510,11 @@ static int run_cfg(int cfg, int splits, const _Float16* A, const _Float16* W, co
         case 5: case 6: case 7: case 8: return gemm8_dispatch(cfg - 4, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         case 9: return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         case 10: return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        case 12: return lin_strip_dispatch(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, st);
+        case 12:
+            // the strip kernel's last weight tile is moved back when N % 128 != 0 and re-reads the residual of the overlapped columns: with an
+            // in-place residual (resid == C) those columns would get it twice -> such a call takes the tiled kernel
+            if (resid == C && N % 128 != 0) return run_cfg((N % 128 == 0 || N > 192) ? 1 : 3, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+            return lin_strip_dispatch(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, st);
     }
     return TCL_EINVAL;
 }
@@ -683,6 +688,7 @@ int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* res
                  int ldc, int ldr, int act, hipStream_t st) {
     TCL_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && lda >= K && ldw % 8 == 0 && ldw >= K && act >= 0 && act <= 5);
     ConvP cp = {};
+    TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * N * K);
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
                     ldw, ldc, ldr, act, cp, st);
 }
@@ -699,6 +705,7 @@ int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* 
     cp.Wout = pad ? (cp.Wup + 2 - 3) / stride + 1 : (cp.Wup + 1 - 3) / stride + 1;
     cp.sy = (float)Hin / (float)cp.Hup; cp.sx = (float)Win / (float)cp.Wup;
     const int M = B * cp.Hout * cp.Wout;
+    TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * Cout * 9.0 * Cin);
     return dispatch((const _Float16*)X, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)Y, M, Cout,
                     9 * Cin, 0, 9 * Cin, Cout, Cout, act, cp, st);
 }

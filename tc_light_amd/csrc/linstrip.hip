@@ -11,6 +11,7 @@
 // epilogue arithmetic (f16(act(acc + bias)), then f16(post_act(. + resid)); GEGLU on the [32 value | 32 gate] row groups of unet.py::_geglu_rows).
 #include "common.h"
 #include "gemm_conv.h"
+#include "prof.h"
 #include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -250,6 +251,8 @@ int tcl_ln_gemm_f16(const void* x, const void* gamma, const void* beta, float ep
     TCL_CHECK_ARG(x && gamma && beta && W && C && M > 0 && act >= 0 && act <= 5 && (act != 2 || !resid));
     ConvP cp = {};
     TCL_CHECK_ARG(lin_strip_ok(M, N, K, ldx, ldw, ldc, ldr, resid != nullptr, act, cp) && ldx >= K && ldw >= K);
+    TCL_CHECK_ARG(!(resid == C && N % 128 != 0));      // no in-place residual when the last weight tile is moved back (its columns are visited twice)
+    TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * N * K);
     return lin_strip_dispatch((const _Float16*)x, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, ldx, ldw, ldc,
                               ldr, act, st, (const _Float16*)gamma, (const _Float16*)beta, eps);
 }

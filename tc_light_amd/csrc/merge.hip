@@ -10,6 +10,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/tclight_hip.h"
+#include "prof.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
@@ -482,6 +483,7 @@ size_t tcl_tome_match_workspace_bytes(int na) { return 4096 + ((size_t)na * 8 + 
 static int tome_match_impl(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                            int* mrg, int* unm, void* ws, int affine, int a_split, int a_gap, int b0, hipStream_t st) {
     TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
+    TclProfScope ps(TCL_PROF_MATCH, st, 2.0 * na * nb * C * Bt);
     // ws: [histograms 512 ints + 2 selector words | keys na x 8 B | aux]; histograms and keys are all-zero on entry (the caller zeroes the
     // workspace once) and are left all-zero -- the histograms sit at a FIXED offset so that a workspace re-used for a different na never
     // maps them onto a previous call's (non-zero) aux words

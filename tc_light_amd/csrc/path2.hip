@@ -677,10 +677,24 @@ int tcl_scatter_mean_rgb2sh(const float* img, const int* inv, float* feat, float
     hipLaunchKernelGGL(k_scatter_final, dim3(stream_grid((long)K * 3, 256, 4)), dim3(256), 0, st, feat, cnt, K);
     TCL_LAUNCH_RET();
 }
+// Small host tables reach the device as KERNEL ARGUMENTS (copied at launch time): no pageable-memory hipMemcpyAsync whose source must outlive
+// the call, no host synchronisation inside the library.
+struct TabChunk { float v[512]; };
+__global__ void k_fill_table(float* dst, int n, TabChunk c) { const int i = threadIdx.x; if (i < n) dst[i] = c.v[i]; }
+__global__ void k_set_i32(int* dst, int v) { *dst = v; }
+static int upload_table(float* dst, const float* src, size_t n, hipStream_t st) {
+    for (size_t o = 0; o < n; o += 512) {
+        TabChunk c;
+        const int m = (int)(n - o < 512 ? n - o : 512);
+        for (int i = 0; i < m; ++i) c.v[i] = src[o + i];
+        hipLaunchKernelGGL(k_fill_table, dim3(1), dim3(512), 0, st, dst + o, m, c);
+    }
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
 int tcl_track_ids_unique(const int* unq_inv, int N, int H, int W, size_t K, int* scratch, int* result, hipStream_t st) {
     TCL_CHECK_ARG(unq_inv && scratch && result && N > 0 && H > 0 && W > 0 && K > 0);
-    const int one = 1, P = H * W;
-    if (hipMemcpyAsync(result, &one, 4, hipMemcpyHostToDevice, st) != hipSuccess) return TCL_ELAUNCH;
+    const int P = H * W;
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, st, result, 1);
     for (int f = 0; f < N; ++f) {
         hipLaunchKernelGGL(k_ids_mark, pgrid(P, 1), dim3(256), 0, st, unq_inv + (size_t)f * P, P, scratch);
         hipLaunchKernelGGL(k_ids_check, pgrid(P, 1), dim3(256), 0, st, unq_inv + (size_t)f * P, P, scratch, result);
@@ -890,11 +904,10 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
     if (lazy) {
         t_last = (int*)lazy_ws;
         bc1 = (float*)((char*)lazy_ws + ((K * 4 + 255) & ~(size_t)255)); bc2 = bc1 + (iters + 1);
-        static std::vector<float> tab;                                       // bias corrections of steps 1 .. iters, as tcl_adam_step computes them
-        tab.assign(2 * (size_t)(iters + 1), 1.f);
+        std::vector<float> tab(2 * (size_t)(iters + 1), 1.f);                // bias corrections of steps 1 .. iters, as tcl_adam_step computes them
         for (int sidx = 1; sidx <= iters; ++sidx) { tab[sidx] = (float)(1.0 - pow((double)0.9f, sidx)); tab[iters + 1 + sidx] = (float)sqrt(1.0 - pow((double)0.999f, sidx)); }   // (double)b1 of the FLOAT b1, like tcl_adam_step
         if (hipMemsetAsync(t_last, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
-        if (hipMemcpyAsync(bc1, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) return TCL_ELAUNCH;
+        if (upload_table(bc1, tab.data(), tab.size(), st) != TCL_OK) return TCL_ELAUNCH;
     }
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;

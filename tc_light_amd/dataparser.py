@@ -125,10 +125,15 @@ def write_mjpeg_avi(dst, frames_u8, fps=30, quality=95):
         jpgs.append(b.getvalue())
     chunk = lambda cc, data: cc + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
     lst = lambda kind, data: b"LIST" + struct.pack("<I", len(data) + 4) + kind + data
-    us = int(round(1e6 / max(fps, 1)))
+    # one time base for both headers: dwRate / dwScale = fps to 1/1000 (29.97 stays 29.97; NTSC rates become exactly 30000/1001 etc.)
+    scale, rate = 1000, max(int(round(float(fps) * 1000)), 1)
+    for num in (24000, 30000, 60000, 120000):
+        if abs(float(fps) - num / 1001.0) < 5e-3:
+            scale, rate = 1001, num
+    us = int(round(1e6 * scale / rate))
     biggest = max(len(j) for j in jpgs)
-    avih = struct.pack("<14I", us, biggest * max(int(fps), 1), 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)
-    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, 1, max(int(fps), 1), 0, n, biggest, 0xFFFFFFFF, 0, 0, 0, w, h)
+    avih = struct.pack("<14I", us, biggest * max(int(round(fps)), 1), 0, 0x10, n, 0, 1, biggest, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, n, biggest, 0xFFFFFFFF, 0, 0, 0, w, h)
     strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
     hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
     movi, idx, off = b"", b"", 4

@@ -23,8 +23,27 @@ from .hostlogic import shard_range
 
 
 class Dist:
-    def __init__(self, rank=0, world=1):
+    def __init__(self, rank=0, world=1, timed=False):
         self.rank, self.world = rank, world
+        # timed=True (bench.py, N > 1): every collective is bracketed by a device synchronise and the host clock, so a scaling run can say
+        # how long the ranks sat in collectives (waiting for the slowest rank included) and how many bytes each one moved.  ~3 per denoising step.
+        self.timed = timed
+        self.stats = {}
+
+    def _coll(self, name, nbytes, fn):
+        if not self.timed:
+            return fn()
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        s = self.stats.setdefault(name, {"calls": 0, "seconds": 0.0, "bytes": 0})
+        s["calls"] += 1; s["seconds"] += time.perf_counter() - t0; s["bytes"] += int(nbytes)
+        return out
+
+    def reset_stats(self):
+        self.stats = {}
 
     @classmethod
     def from_env(cls):
@@ -43,7 +62,7 @@ class Dist:
         pad = torch.zeros((nmax,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
         pad[:x_local.shape[0]] = x_local
         out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(out, pad)
+        self._coll("all_gather_frames", pad.numel() * pad.element_size() * self.world, lambda: dist.all_gather(out, pad))
         parts = []
         for r in range(self.world):
             lo, hi = shard_range(n_total, r, self.world)
@@ -57,12 +76,12 @@ class Dist:
     def reduce_full(self, full):
         """Sum the per-rank partially filled full-size tensors (disjoint support) in place."""
         if self.world > 1:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            self._coll("all_reduce_yt_noise", full.numel() * full.element_size(), lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM))
         return full
 
     def all_reduce_sum(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self._coll("all_reduce", t.numel() * t.element_size(), lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         return t
 
     def reduce_scatter_sum(self, full, out):
@@ -71,9 +90,9 @@ class Dist:
         if self.world == 1:
             out.copy_(full)
         elif dist.get_backend() == "nccl":
-            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+            self._coll("reduce_scatter", full.numel() * full.element_size(), lambda: dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM))
         else:
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            self._coll("reduce_scatter", full.numel() * full.element_size(), lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM))
             n = out.numel()
             out.copy_(full[self.rank * n:(self.rank + 1) * n])
         return out
@@ -83,7 +102,7 @@ class Dist:
         if self.world == 1:
             full.copy_(shard)
         else:
-            dist.all_gather_into_tensor(full, shard)
+            self._coll("all_gather_rows", full.numel() * full.element_size(), lambda: dist.all_gather_into_tensor(full, shard))
         return full
 
     def barrier(self):

@@ -49,9 +49,12 @@ def load_gemm_table(L):
         L.tcl_gemm_autotune(0)
         return
     path = os.environ.get("TCL_GEMM_TABLE", GEMM_TABLE)
-    if os.path.exists(path) and L.tcl_gemm_tune_load(path) != 0:
-        import warnings
-        warnings.warn(f"GEMM tile table {path} was written for other kernels (no / other version line): ignored, shapes are timed on first use")
+    if os.path.exists(path):
+        try:                    # (the ctypes binding raises on a non-zero return code: an unversioned / foreign table is TCL_EINVAL)
+            L.tcl_gemm_tune_load(path)
+        except RuntimeError:
+            import warnings
+            warnings.warn(f"GEMM tile table {path} was written for other kernels (no / other version line): ignored, shapes are timed on first use")
     L.tcl_gemm_autotune(2 if mode == "table" else 1)
 
 

@@ -227,7 +227,9 @@ class VidToMe:
             if self.trace is not None:
                 self.trace.append(dict(name=name, F=F, unm=unm1, gather=mrg1, mrg1=mrg1, T=TL))
             return local, unm1, TL
-        assert bank.shape[0] == ne, "a block's bank was seeded with another number of batch entries (reset_global_tokens() between modes)"
+        if bank.shape[0] != ne:       # (a real exception: `python -O` strips asserts and a 2-entry gather would then read past a 1-entry bank)
+            raise RuntimeError(f"VidToMe bank of block {name!r} was seeded with {bank.shape[0]} batch entr{'y' if bank.shape[0] == 1 else 'ies'}, this call "
+                               f"carries {ne}: call reset_global_tokens() when switching between forward_many(cfg_pair=True) and the two-entry paths")
         Tb = bank.shape[1]
         if self.coin > a["global_rand"]:                                        # patch.py:61-65: local tokens are src
             src_len, loff, boff = TL, 0, TL

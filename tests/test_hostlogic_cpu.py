@@ -58,3 +58,16 @@ def test_shard_track_ids_equal_fresh_flowid():
         # same partition <=> the pairing (local id, fresh id) is one-to-one
         pairs = torch.unique(torch.stack([local, fresh], 1), dim=0)
         assert pairs.shape[0] == local.max().item() + 1 == fresh.max().item() + 1
+
+
+def test_bench_gpus_n_without_gpu_fails_loudly():
+    """`python bench.py --gpus 2` on a box without GPUs must say so (exit != 0, one clear line) -- never run a silent 1-rank or CPU pass."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)

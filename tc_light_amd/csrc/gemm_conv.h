@@ -46,6 +46,10 @@ __device__ __forceinline__ float post_act(float v, int act) { return act == 5 ? 
 
 int gemm8_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st);
+// 8-phase 256-row kernels (gemm8q.hip): cfg 1 = 256 x 256, 2 = 256 x 320
+bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp);
+int gemm8q_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
+                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st);
 // strip-resident K = 320 Linear (linstrip.hip), cfg 12
 bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp);
 int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,

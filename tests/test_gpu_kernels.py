@@ -343,8 +343,9 @@ def test_gemm_fused_geglu(L):
 @pytest.mark.parametrize("shape", [("g", 5520, 1280, 1280), ("g", 21600, 640, 640), ("g", 1472, 1280, 2560), ("g", 33333, 960, 320),
                                    ("g", 20001, 352, 320), ("c", 8, 23, 30, 640, 640), ("c", 8, 4, 12, 1280, 1280)])
 def test_gemm_configs_bit_identical(L, shape):
-    """Every tile configuration (LDS-DMA 128x128 / 64x128 / 128x64 / 64x64 / 256x128 and the 8-wave 256x320 / 128x320 / 256x256 /
-    128x256 kernels; for K = 320 the strip-resident Linear of csrc/linstrip.hip, cfg 12, whose MFMA operand roles are swapped)
+    """Every tile configuration (LDS-DMA 128x128 / 64x128 / 128x64 / 64x64 / 256x128, the 8-wave 256x320 / 128x320 / 256x256 /
+    128x256 kernels, the round-4 8-phase 256x256 / 256x320 kernels of csrc/gemm8q.hip -- cfg 13 / 14, 16x16x32 MFMAs with the weight
+    fragment as the row operand; for K = 320 the strip-resident Linear of csrc/linstrip.hip, cfg 12, whose MFMA operand roles are swapped)
     accumulates each output in the same k order, so with equal K splits the results are bit-identical -- the property the automatic
     configuration choice relies on -- and the automatic choice itself matches them."""
     ws = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
@@ -375,8 +376,8 @@ def test_gemm_configs_bit_identical(L, shape):
     try:
         for splits in (1, 4):
             outs = {}
-            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8, 12):
-                if splits > 1 and cfg in (5, 6, 7, 8, 12):
+            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14):
+                if splits > 1 and cfg in (5, 6, 7, 8, 12, 13, 14):
                     continue
                 L.tcl_gemm_tune(cfg, splits)
                 try:
@@ -394,6 +395,57 @@ def test_gemm_configs_bit_identical(L, shape):
     finally:
         L.tcl_gemm_tune(0, 0)
         L.tcl_set_workspace(0, 0)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", ["silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "conv_s2", "conv_s2_pad0", "conv_silu_resid"])
+def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
+    """The 8-phase kernels (cfg 13 = 256x256, 14 = 256x320; csrc/gemm8q.hip) against the LDS-DMA tile kernel (cfg 1) and the round-3 8-wave
+    kernel (cfg 7, GEGLU) on what test_gemm_configs_bit_identical does not reach: every epilogue (SiLU, GELU after the residual, GEGLU in
+    registers), K = one / two / five K tiles (prologue and tail paths of the two-buffer ring), fewer rows than one tile, stride-2 convolutions
+    with symmetric and with the VAE encoder's asymmetric padding (tap masks), a convolution with activation + residual.  Bit equality."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(H)
+    ref_cfg = 1
+    if case in ("silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu"):
+        M, N, K, act, hasr = {"silu": (3000, 1280, 640, 1, False), "gelu_after_resid": (2049, 1280, 1280, 5, True), "k64": (777, 1280, 64, 0, True),
+                              "k128": (1025, 1280, 128, 4, False), "k320_small_m": (100, 1280, 320, 0, True), "geglu": (2500, 2560, 320, 2, False)}[case]
+        A, W, b = mk(M, K), mk(N, K, sc=K ** -0.5), mk(N)
+        R = mk(M, N) if hasr else None
+        No = N // 2 if act == 2 else N
+        if act == 2:
+            ref_cfg = 7
+
+        def run():
+            C = torch.empty(M, No, device="cuda", dtype=H)
+            L.tcl_gemm_f16(A, W, b, R if hasr else 0, C, M, N, K, K, K, No, N, act, st())
+            return C
+        cfgs = (13,) if act == 2 else (13, 14)
+    else:
+        B, Hh, Ww, Ci, Co, stride, pad, act, hasr = {"conv_s2": (3, 46, 30, 640, 640, 2, 1, 0, False), "conv_s2_pad0": (2, 40, 56, 256, 256, 2, 0, 0, False),
+                                                     "conv_silu_resid": (5, 23, 30, 320, 640, 1, 1, 1, True)}[case]
+        Ho = (Hh + 2 - 3) // stride + 1 if pad else (Hh + 1 - 3) // stride + 1
+        Wo = (Ww + 2 - 3) // stride + 1 if pad else (Ww + 1 - 3) // stride + 1
+        x, w, b = mk(B, Hh, Ww, Ci), mk(Co, 9 * Ci, sc=(9 * Ci) ** -0.5), mk(Co)
+        R = mk(B, Ho, Wo, Co) if hasr else None
+
+        def run():
+            y = torch.empty(B, Ho, Wo, Co, device="cuda", dtype=H)
+            L.tcl_conv3x3_f16(x, w, b, R if hasr else 0, y, B, Hh, Ww, Ci, Co, stride, pad, 0, 0, act, st())
+            return y
+        cfgs = (13, 14) if Co % 1280 == 0 else ((13,) if Co % 256 == 0 else (14,))
+        if Co == 640:
+            cfgs = (14,)
+    try:
+        L.tcl_gemm_tune(ref_cfg, 1)
+        ref = run()
+        for cfg in cfgs:
+            L.tcl_gemm_tune(cfg, 1)
+            out = run()
+            assert torch.isfinite(out.float()).all()
+            assert torch.equal(out, ref), f"{case}: cfg {cfg} differs from cfg {ref_cfg} in {(out != ref).sum().item()} of {out.numel()} outputs (max |d| {(out.float() - ref.float()).abs().max().item():.3e})"
+    finally:
+        L.tcl_gemm_tune(0, 0)
     torch.cuda.synchronize()
 
 

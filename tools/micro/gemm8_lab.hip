@@ -7,6 +7,7 @@
 #define G8_PROF
 #endif
 #include "../../tc_light_amd/csrc/gemm8.hip"
+#include "../../tc_light_amd/csrc/gemm8q.hip"
 #include <algorithm>
 #include <stdio.h>
 #include <string.h>
@@ -166,6 +167,32 @@ int main(int argc, char** argv) {
             printf("   cfg %d (%s):", cfg, cfg == 1 ? "256x320" : cfg == 2 ? "128x320" : cfg == 3 ? "256x256" : "128x256");
             for (int sched = 0; sched < 3; ++sched) if ((smask >> sched) & 1) printf("  s%d %8.1f us %6.0f TF (best %6.0f)", sched, med[sched] * 1e3, flop / med[sched] / 1e9, flop / best[sched] / 1e9);
             printf("\n");
+        }
+        // round 4: the 8-phase kernels (gemm8q.hip): bit comparison with the last schedule-0 result in C0, sampled f32 reference, same timing protocol
+        for (int qc = 1; qc <= 2; ++qc) {
+            if (cfgs.empty() || !gemm8q_ok(qc, M, N, K, lda ? lda : 8, K, N, N, false, 0, cp)) continue;
+            CK(hipMemsetAsync(C1, 0xff, (size_t)M * N * 2, st));
+            if (gemm8q_dispatch(qc, A, Wt, nullptr, nullptr, C1, M, N, K, lda, K, N, N, 0, cp, st) != TCL_OK) { printf("q launch failed %d\n", qc); exit(1); }
+            CK(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(k_ref, dim3(32), dim3(256), 0, st, A, Wt, C1, M, N, K, cp, 8192, derr);
+            std::vector<float> herr(8192);
+            CK(hipMemcpyAsync(herr.data(), derr, 8192 * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            float mx = 0; for (float v : herr) mx = std::max(mx, v);
+            unsigned nd = 0;
+            CK(hipMemsetAsync(dcnt, 0, 4, st));
+            hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, st, (const unsigned*)C0, (const unsigned*)C1, (size_t)M * N / 2, dcnt);
+            CK(hipMemcpyAsync(&nd, dcnt, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            if (mx > 2e-2f || nd) printf("   !!! q%d: max rel err vs f32 reference %.3e, words differing from k_gemm8: %u\n", qc, mx, nd);
+            std::vector<float> tq;
+            for (int round = 0; round < 5; ++round) {
+                CK(hipEventRecord(e0, st));
+                for (int r = 0; r < 4; ++r) gemm8q_dispatch(qc, A, Wt, nullptr, nullptr, C1, M, N, K, lda, K, N, N, 0, cp, st);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                tq.push_back(ms / 4);
+            }
+            std::sort(tq.begin(), tq.end());
+            printf("   q%d  (%s, 8-phase):  %8.1f us %6.0f TF (best %6.0f)\n", qc, qc == 1 ? "256x256" : "256x320", tq[2] * 1e3, flop / tq[2] / 1e9, flop / tq[0] / 1e9);
         }
         CK(hipFree(A)); CK(hipFree(Wt)); CK(hipFree(C0)); CK(hipFree(C1));
     }

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <string>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -178,7 +180,6 @@ __global__ __launch_bounds__(512) void k_g8ph(const _Float16* __restrict__ A, co
 }
 
 // ---- the product's 8-wave kernels, for the same-run comparison
-#define G8_LAB_ONLY
 #include "../../tc_light_amd/csrc/gemm8.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -265,7 +266,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpyAsync(&md, dmx, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
                 CK(hipMemsetAsync(dmx, 0, 4, st));
             }
-            float mdf; memcpy(&mdf, &md, 4);
+            float mdf; __builtin_memcpy(&mdf, &md, 4);
             printf("   check %-34s max rel err vs f32 reference (8192 samples) %.2e%s\n", names[v], mx, v >= 2 ? (std::string("   max |x - product| / (|product| + 1) over all outputs, 3 launches: ") + std::to_string(mdf)).c_str() : "");
         }
         for (int round = 0; round < 7; ++round)

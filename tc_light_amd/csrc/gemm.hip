@@ -497,7 +497,7 @@ static int launch_gemm(const _Float16* A, const _Float16* W, const _Float16* bia
 //   5 g8 256x320    6 g8 128x320   7 g8 256x256   8 g8 128x256                      (gemm8.hip, 8-wave ping-pong)
 //   9 reg 128x128   10 reg 128x64                                                    (k_gemm, register-staged; any N / ld)
 //   12 strip-resident K = 320 Linear (linstrip.hip: 128 activation rows in registers, weight rows swept through LDS)
-//   13 q8 256x256   14 q8 256x320                                                    (gemm8q.hip, 8-phase 256-row kernels, round 4)
+//   13 q8 256x256   14 q8 256x320   15 q8 512x128                                                    (gemm8q.hip, 8-phase 256-row kernels, round 4)
 static int g_tune_cfg = 0, g_tune_splits = 0;
 
 static int run_cfg(int cfg, int splits, const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N,
@@ -511,7 +511,7 @@ static int run_cfg(int cfg, int splits, const _Float16* A, const _Float16* W, co
         case 5: case 6: case 7: case 8: return gemm8_dispatch(cfg - 4, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         case 9: return launch_gemm<128, 128, 2, 2, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         case 10: return launch_gemm<128, 64, 4, 1, 1>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
-        case 13: case 14: return gemm8q_dispatch(cfg - 12, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+        case 13: case 14: case 15: return gemm8q_dispatch(cfg - 12, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
         case 12:
             // the strip kernel's last weight tile is moved back when N % 128 != 0 and re-reads the residual of the overlapped columns: with an
             // in-place residual (resid == C) those columns would get it twice -> such a call takes the tiled kernel
@@ -526,7 +526,7 @@ static bool cfg_ok(int cfg, int M, int N, int K, int ldc, int ldr, bool has_resi
     if (cfg == 9 || cfg == 10) return act != 2 || cfg == 9;
     if (!vec_ok) return false;
     if (cfg == 12) return lin_strip_ok(M, N, K, 8, 8, ldc, ldr, has_resid, act, cp);     // lda / ldw: multiples of 8 by tcl_gemm_f16's argument check
-    if (cfg == 13 || cfg == 14) return gemm8q_ok(cfg - 12, M, N, K, 8, 8, ldc, ldr, has_resid, act, cp);
+    if (cfg >= 13 && cfg <= 15) return gemm8q_ok(cfg - 12, M, N, K, 8, 8, ldc, ldr, has_resid, act, cp);
     if (cfg >= 5 && cfg <= 8) return (act != 2 || cfg >= 7) && K % 64 == 0 && (!cp.conv || cp.Cin % 64 == 0);   // GEGLU: 64-column wave strips only
     if (act == 2) return true;                                          // GEGLU epilogue: 64-column [value | gate] groups, every BN is a multiple
     return true;
@@ -548,6 +548,7 @@ static bool tile_ok(int cfg, int M, int N, int K, int splits) {
         case 12: return splits == 1 && K == 320 && N >= 128 && M >= 16384;
         case 13: return splits == 1 && K >= 320 && N % 256 == 0 && cdiv(M, 256) * (N / 256) >= 96;
         case 14: return splits == 1 && K >= 320 && N % 320 == 0 && cdiv(M, 256) * (N / 320) >= 96;
+        case 15: return splits == 1 && K >= 320 && N % 128 == 0 && N % 256 != 0 && cdiv(M, 512) * (N / 128) >= 96;
     }
     return false;
 }
@@ -618,14 +619,14 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     if (g_autotune == 2)      // table-only mode: shapes the loaded table does not know take the static heuristic (no timing, no host sync)
         return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs (tile_ok)
-    int cand[12], nc = 0;
-    static const int all_cfgs[12] = {1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14};
+    int cand[13], nc = 0;
+    static const int all_cfgs[13] = {1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14, 15};
     for (int c : all_cfgs)
         if (tile_ok(c, M, N, K, splits)) cand[nc++] = c;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     // two interleaved rounds, minimum per candidate: one disturbed measurement (clock ramp, a profiler attached) must not pick the tile
-    float t_ms[12]; bool ok[12];
+    float t_ms[13]; bool ok[13];
     for (int i = 0; i < nc; ++i) {
         t_ms[i] = 1e30f;
         ok[i] = cfg_ok(cand[i], M, N, K, ldc, ldr, hasr, act, cp) &&
@@ -681,7 +682,7 @@ int tcl_gemm_tune_load(const char* path) {
         if (line[0] == '#') continue;
         if (!versioned) { fclose(f); return TCL_EINVAL; }          // a table of another kernel generation / architecture: measured with other tiles
         if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d %d", &k.conv, &k.M, &k.N, &k.K, &k.act, &k.hasr, &k.Hin, &k.Win, &k.Cin, &k.stride, &k.Hup, &cfg) != 12) continue;
-        if (!((cfg >= 1 && cfg <= 8) || (cfg >= 11 && cfg <= 14))) continue;         // only ids the cached path may run
+        if (!((cfg >= 1 && cfg <= 8) || (cfg >= 11 && cfg <= 15))) continue;         // only ids the cached path may run
         g_tune_cache[k] = cfg;
     }
     fclose(f);

@@ -23,7 +23,7 @@
 //     P0(t): last read G1 tick 1, retired before the barrier ending tick 1 (counted lgkmcnt) -> restaged by G0 in tick 2.
 //     S0(t): last read G1 tick 1, retired (lgkmcnt 0) in tick 2 -> restaged G0 tick 4.   P1(t): G1 tick 3 -> G0 tick 6.   S1(t): G1 tick 5 -> G0 tick 8.
 //     G1's phase-4 wait sits before the barrier ending tick 7; the first read of tile t+1 is G0's in tick 8.
-//   * configurations: 256 x 256 (WM 2, WN 4: quadrant 64 x 32, P = B: the guide's geometry; also the GEGLU feed-forwards -- a wave's 64 columns
+//   * configurations (+ 512 x 128, WM 8 x WN 1, quadrant 32 x 64, for the VAE's 128-channel layers): 256 x 256 (WM 2, WN 4: quadrant 64 x 32, P = B: the guide's geometry; also the GEGLU feed-forwards -- a wave's 64 columns
 //     are one [32 value | 32 gate] group, combined in registers) and 256 x 320 (WM 4, WN 2: quadrant 32 x 80, P = A: every UNet width is a
 //     multiple of 320);
 //   * LDS image: row R of a half-tile <-> logical row (R / Q) * 2Q + h * Q + R % Q (Q = QM | QN), 16-B chunk index XOR (R >> 1) & 7 applied on the
@@ -52,11 +52,12 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(WM * WN == 8, "8 waves");
     constexpr int QM = RI * 16, QN = CJ * 16, BM = 2 * WM * QM, BN = 2 * WN * QN;
-    static_assert(BM == 256, "256-row tiles");
+    static_assert(BM == 256 || BM == 512, "256- / 512-row tiles");
     constexpr bool PB = CJ <= RI;                               // the persistent operand is B (else A)
     constexpr int HB = WN * QN;                                 // rows of a B half-tile
-    constexpr int A_HALF = 128 * 128, B_HALF = HB * 128, BUF = 2 * A_HALF + 2 * B_HALF;
-    constexpr int NA = 2, NB = (B_HALF + 8191) / 8192;          // LDS-DMA instructions per wave and half-tile
+    constexpr int A_HALF = WM * QM * 128, B_HALF = HB * 128, BUF = 2 * A_HALF + 2 * B_HALF;
+    constexpr int NA = A_HALF / 8192, NB = (B_HALF + 8191) / 8192;      // LDS-DMA instructions per wave and half-tile
+    static_assert(A_HALF % 8192 == 0, "whole A passes");
     constexpr int NRP = PB ? 2 * CJ : 2 * RI, NRS = PB ? 2 * RI : 2 * CJ;      // ds_read_b128 per persistent / streamed sub-tile
     constexpr bool RR = !PB;                                    // re-read P0 in phase 4 instead of keeping both P halves in registers
     constexpr int NP_ = PB ? NB : NA, NS_ = PB ? NA : NB;       // loads per stage of the persistent / streamed operand
@@ -78,9 +79,11 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
     // ---- staging: thread <-> (LDS row R = 64 p + (tid >> 3), chunk' = tid & 7) of a half-tile; source chunk = chunk' ^ ((R >> 1) & 7)
     const int srow = tid >> 3;
     const unsigned csrc = (unsigned)(((tid & 7) ^ ((srow >> 1) & 7)) * 16);
-    unsigned aoff[2][2]; unsigned amask[2] = {0u, 0u};           // [pass][half]; conv: per pass 2 x 9 tap bits
+    unsigned aoff[NA][2]; unsigned amask[NA];                    // [pass][half]; conv: per pass 2 x 9 tap bits
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < NA; ++p) amask[p] = 0u;
+#pragma unroll
+    for (int p = 0; p < NA; ++p)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int R = 64 * p + srow, m = m0 + (R / QM) * (2 * QM) + h * QM + R % QM;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
 #define Q_STAGE_A(H, U)                                                                                                       \
     {                                                                                                                         \
         char* d_ = sdst + ((U) & 1) * BUF + (H) * A_HALF;                                                                     \
-        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                                   \
+        _Pragma("unroll") for (int p_ = 0; p_ < NA; ++p_) {                                                                  \
             if (!CONV) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, Q_LDS(d_ + p_ * 8192), 16, aoff[p_][H], s_ka, 0, 0);      \
             else {                                                                                                            \
                 const unsigned vo_ = ((amask[p_] >> (9 * (H) + s_tap)) & 1u) ? aoff[p_][H] + s_ka : 0xffffffffu;       \
@@ -332,9 +335,9 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
 template <int WM, int WN, int RI, int CJ>
 static int launch8q(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K, int lda,
                     int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
-    constexpr int QN = CJ * 16, BN = 2 * WN * QN, B_HALF = WN * QN * 128;
-    const int tm = cdiv(M, 256), tn = N / BN;
-    const size_t lds = (size_t)2 * (2 * 16384 + 2 * B_HALF) + 4096;
+    constexpr int QN = CJ * 16, BN = 2 * WN * QN, B_HALF = WN * QN * 128, BM = 2 * WM * RI * 16, A_HALF = WM * RI * 16 * 128;
+    const int tm = cdiv(M, BM), tn = N / BN;
+    const size_t lds = (size_t)2 * (2 * A_HALF + 2 * B_HALF) + (B_HALF % 8192 ? 4096 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_gemm8q<WM, WN, RI, CJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -348,10 +351,11 @@ static int launch8q(const _Float16* A, const _Float16* W, const _Float16* bias, 
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
-// Can the 8-phase kernel take this call?  cfg 1 = 256 x 256 (N % 256 == 0; GEGLU allowed), 2 = 256 x 320 (N % 320 == 0).  K % 64 == 0 (conv:
+// Can the 8-phase kernel take this call?  cfg 1 = 256 x 256 (N % 256 == 0; GEGLU allowed), 2 = 256 x 320 (N % 320 == 0), 3 = 512 x 128 (N % 128 == 0:
+// the VAE's 128-channel convolutions at full resolution; WM 8, WN 1, quadrant 32 x 64, all 160 KiB of LDS).  K % 64 == 0 (conv:
 // Cin % 64 == 0), operands addressable with 32 bits, no nearest-upsampling gather (those convolutions stay on k_gemm8s), 16-B aligned rows.
 bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
-    const int BN = cfg == 1 ? 256 : 320;
+    const int BN = cfg == 1 ? 256 : (cfg == 2 ? 320 : 128);
     if (N % BN || K % 64 || K < 64 || M < 1) return false;
     if ((ldw & 7) || (ldc & 7) || (has_resid && (ldr & 7))) return false;
     if (act == 2 && (cfg != 1 || has_resid)) return false;
@@ -369,5 +373,6 @@ int gemm8q_dispatch(int cfg, const _Float16* A, const _Float16* W, const _Float1
                     int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
     if (!gemm8q_ok(cfg, M, N, K, lda, ldw, ldc, ldr, resid != nullptr, act, cp)) return TCL_EINVAL;
     if (cfg == 1) return launch8q<2, 4, 4, 2>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    if (cfg == 3) return launch8q<8, 1, 2, 4>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     return launch8q<4, 2, 2, 5>(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
 }

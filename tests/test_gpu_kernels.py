@@ -341,10 +341,11 @@ def test_gemm_fused_geglu(L):
 
 
 @pytest.mark.parametrize("shape", [("g", 5520, 1280, 1280), ("g", 21600, 640, 640), ("g", 1472, 1280, 2560), ("g", 33333, 960, 320),
-                                   ("g", 20001, 352, 320), ("c", 8, 23, 30, 640, 640), ("c", 8, 4, 12, 1280, 1280)])
+                                   ("g", 20001, 352, 320), ("c", 8, 23, 30, 640, 640), ("c", 8, 4, 12, 1280, 1280),
+                                   ("g", 9001, 384, 640), ("c", 3, 40, 56, 128, 128)])
 def test_gemm_configs_bit_identical(L, shape):
     """Every tile configuration (LDS-DMA 128x128 / 64x128 / 128x64 / 64x64 / 256x128, the 8-wave 256x320 / 128x320 / 256x256 /
-    128x256 kernels, the round-4 8-phase 256x256 / 256x320 kernels of csrc/gemm8q.hip -- cfg 13 / 14, 16x16x32 MFMAs with the weight
+    128x256 kernels, the round-4 8-phase 256x256 / 256x320 / 512x128 kernels of csrc/gemm8q.hip -- cfg 13 / 14 / 15, 16x16x32 MFMAs with the weight
     fragment as the row operand; for K = 320 the strip-resident Linear of csrc/linstrip.hip, cfg 12, whose MFMA operand roles are swapped)
     accumulates each output in the same k order, so with equal K splits the results are bit-identical -- the property the automatic
     configuration choice relies on -- and the automatic choice itself matches them."""
@@ -376,8 +377,8 @@ def test_gemm_configs_bit_identical(L, shape):
     try:
         for splits in (1, 4):
             outs = {}
-            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14):
-                if splits > 1 and cfg in (5, 6, 7, 8, 12, 13, 14):
+            for cfg in (1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14, 15):
+                if splits > 1 and cfg in (5, 6, 7, 8, 12, 13, 14, 15):
                     continue
                 L.tcl_gemm_tune(cfg, splits)
                 try:
@@ -398,18 +399,19 @@ def test_gemm_configs_bit_identical(L, shape):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", ["silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "conv_s2", "conv_s2_pad0", "conv_silu_resid"])
+@pytest.mark.parametrize("case", ["silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "conv_s2", "conv_s2_pad0", "conv_silu_resid", "n128_silu_resid", "conv_n128_s2_pad0"])
 def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
-    """The 8-phase kernels (cfg 13 = 256x256, 14 = 256x320; csrc/gemm8q.hip) against the LDS-DMA tile kernel (cfg 1) and the round-3 8-wave
+    """The 8-phase kernels (cfg 13 = 256x256, 14 = 256x320, 15 = 512x128; csrc/gemm8q.hip) against the LDS-DMA tile kernel (cfg 1) and the round-3 8-wave
     kernel (cfg 7, GEGLU) on what test_gemm_configs_bit_identical does not reach: every epilogue (SiLU, GELU after the residual, GEGLU in
     registers), K = one / two / five K tiles (prologue and tail paths of the two-buffer ring), fewer rows than one tile, stride-2 convolutions
     with symmetric and with the VAE encoder's asymmetric padding (tap masks), a convolution with activation + residual.  Bit equality."""
     g = torch.Generator(device="cuda").manual_seed(11)
     mk = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(H)
     ref_cfg = 1
-    if case in ("silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu"):
+    if case in ("silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "n128_silu_resid"):
         M, N, K, act, hasr = {"silu": (3000, 1280, 640, 1, False), "gelu_after_resid": (2049, 1280, 1280, 5, True), "k64": (777, 1280, 64, 0, True),
-                              "k128": (1025, 1280, 128, 4, False), "k320_small_m": (100, 1280, 320, 0, True), "geglu": (2500, 2560, 320, 2, False)}[case]
+                              "k128": (1025, 1280, 128, 4, False), "k320_small_m": (100, 1280, 320, 0, True), "geglu": (2500, 2560, 320, 2, False),
+                              "n128_silu_resid": (5000, 128, 448, 1, True)}[case]
         A, W, b = mk(M, K), mk(N, K, sc=K ** -0.5), mk(N)
         R = mk(M, N) if hasr else None
         No = N // 2 if act == 2 else N
@@ -420,10 +422,11 @@ def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
             C = torch.empty(M, No, device="cuda", dtype=H)
             L.tcl_gemm_f16(A, W, b, R if hasr else 0, C, M, N, K, K, K, No, N, act, st())
             return C
-        cfgs = (13,) if act == 2 else (13, 14)
+        cfgs = (13,) if act == 2 else ((15,) if N == 128 else (13, 14))
     else:
         B, Hh, Ww, Ci, Co, stride, pad, act, hasr = {"conv_s2": (3, 46, 30, 640, 640, 2, 1, 0, False), "conv_s2_pad0": (2, 40, 56, 256, 256, 2, 0, 0, False),
-                                                     "conv_silu_resid": (5, 23, 30, 320, 640, 1, 1, 1, True)}[case]
+                                                     "conv_silu_resid": (5, 23, 30, 320, 640, 1, 1, 1, True),
+                                                     "conv_n128_s2_pad0": (2, 44, 60, 128, 128, 2, 0, 0, False)}[case]
         Ho = (Hh + 2 - 3) // stride + 1 if pad else (Hh + 1 - 3) // stride + 1
         Wo = (Ww + 2 - 3) // stride + 1 if pad else (Ww + 1 - 3) // stride + 1
         x, w, b = mk(B, Hh, Ww, Ci), mk(Co, 9 * Ci, sc=(9 * Ci) ** -0.5), mk(Co)
@@ -436,6 +439,8 @@ def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
         cfgs = (13, 14) if Co % 1280 == 0 else ((13,) if Co % 256 == 0 else (14,))
         if Co == 640:
             cfgs = (14,)
+        if Co == 128:
+            cfgs = (15,)
     try:
         L.tcl_gemm_tune(ref_cfg, 1)
         ref = run()

@@ -6,17 +6,17 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # round 2: the default bench IS the metric's configuration (300 frames 1280x720, --steps 20 --warmup 5); ~3e6 kernel records
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --no_cpu_baseline --no_extras > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --no_cpu_baseline --no_extras --profile_steps 0 > $OUT/bench_under_rocprof.json 2> /dev/null
 python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/kt 60 --timed-pass > $OUT/bench_kernel_stats.txt
 rm -rf /tmp/kt
 if [ "$2" = "exclusive" ]; then
 # the same with the matching chain on the main stream: per-kernel durations of kernels that have the GPU to themselves
-TCL_TOME_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/ktx -o kt -- python $GRAFT_REPO_ROOT/bench.py --no_cpu_baseline --no_extras > $OUT/bench_under_rocprof_exclusive.json 2> /dev/null
+TCL_TOME_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/ktx -o kt -- python $GRAFT_REPO_ROOT/bench.py --no_cpu_baseline --no_extras --profile_steps 0 > $OUT/bench_under_rocprof_exclusive.json 2> /dev/null
 python $GRAFT_REPO_ROOT/tools/prof_summary.py /tmp/ktx 60 --timed-pass > $OUT/bench_kernel_stats_exclusive.txt
 rm -rf /tmp/ktx
 fi
 for c in FETCH_SIZE WRITE_SIZE; do     # separate counter passes, 2 denoising steps of the same workload (60 of the 300 frames keep them short)
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $GRAFT_REPO_ROOT/bench.py --frames 60 --steps 2 --warmup 0 --no_cpu_baseline --no_extras --epochs 0 --epochs_exposure 1 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $GRAFT_REPO_ROOT/bench.py --frames 60 --steps 2 --warmup 0 --no_cpu_baseline --no_extras --epochs 0 --epochs_exposure 1 --profile_steps 0 > /dev/null 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/pmc_traffic.py /tmp/pm_FETCH_SIZE/pm_counter_collection.csv /tmp/pm_WRITE_SIZE/pm_counter_collection.csv k_flashILi40 k_flashILi40ELi48ELi64ELi2ELi4ELi2ELi0ELi0E > $OUT/flash40_traffic.json
 cat $OUT/flash40_traffic.json; tail -1 $OUT/bench_under_rocprof.json | cut -c1-300

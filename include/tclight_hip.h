@@ -211,7 +211,8 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
  * Outputs: mrg[na-r+nb] = input position feeding each merged slot ([unmerged src | dst], mode "replace");
  *          unm[position] = merged slot each input position is restored from (merge.py:135-155).
  * ws: tcl_tome_match_workspace_bytes(na) bytes, ZEROED ONCE by the caller before the first call and then only passed to this function
- * (one stream; may be re-used for any smaller na): every call leaves its zero-on-entry part (histograms + keys) all-zero again. */
+ * (one stream; may be re-used for any smaller na): every call leaves it all-zero again except two result words at a fixed offset (layout:
+ * 4 KiB control | 65 536 score-histogram bins | keys).  Per call: the score kernel + two small launches (threshold select, maps). */
 size_t tcl_tome_match_workspace_bytes(int na);
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st);

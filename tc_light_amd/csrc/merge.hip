@@ -308,138 +308,122 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
     if (hl == 0 && si < na) atomicMax(keys + si, best);
 }
 
-// Top-r selection and map construction without a sort (replaces key extraction + device radix sort + map building, ~8 launches per match,
-// by 3 small ones).  The r src tokens with the highest f16 score are merged, ties at the threshold go to the lowest src index
-// (= the order a stable descending sort would produce); the reference orders the remaining (unmerged) src slots by score as well, but
-// that order is immaterial -- the merged sequence only feeds a permutation-invariant attention and is mapped back by `unm` -- so they keep
-// their src index order here.  Maps of SURVEY 8(a) A12/A13:
+// Top-r selection and map construction without a sort, in TWO launches per match (round 4; rounds 2-3: five -- two histogram passes, two
+// single-block picks, the map kernel -- ~650 k launches per 300-frame pass).  The r src tokens with the highest f16 score are merged, ties at the
+// threshold go to the lowest src index (= the order a stable descending sort would produce); the reference orders the remaining (unmerged) src
+// slots by score as well, but that order is immaterial -- the merged sequence only feeds a permutation-invariant attention and is mapped back by
+// `unm` -- so they keep their src index order here.  Maps of SURVEY 8(a) A12/A13:
 //  mrg[p]  (p in [0, na-r+nb))  = input position feeding merged slot p          (merge, mode "replace")
 //  unm[pos] (pos in input seq)  = merged slot that input position pos is restored from (unmerge)
-// pass 1: threshold score of the r-th largest element and, for every chunk of PER consecutive src indices, the number of ties / lower
-// scores before it (exclusive scans) -> aux.  Four SMALL launches (256-thread blocks, < 40 VGPRs, <= 8 KiB LDS) instead of one 1024-thread
-// block holding every score in registers: in the pipeline this chain runs on a side stream beside the flash kernel, whose two blocks per
-// CU hold 444 of a SIMD's 512 registers and 132 of the 160 KiB of LDS -- the big block could only start on a CU that BOTH flash blocks had left
-// (97 us alone, 1 150 us average in the profiled 300-frame pass: 5 % of all kernel time and on the matching chain's critical path); small
-// blocks slip into the register / LDS remainder of any CU.  Two-level radix select on the 16-bit scores: histogram of the high byte
-// (grid; LDS atomics on 256 bins per block, then one global add per bin), pick the bucket that holds the r-th largest (one block),
-// histogram of the low byte inside that bucket (grid), pick the threshold and run the chunk scans (one block, LDS counters + Hillis-Steele).
-// hist: 512 ints, all-zero on entry and left all-zero (the last kernel clears them), like the key array.
+// k_thr_select: ONE histogram over all 65 536 sortable-f16 scores (global atomics, one per src token: the 256 KiB of bins live at a fixed offset
+//   of the workspace and are all-zero between matches); the block that draws the last ticket (guide: "last arriver" hand-off -- writers drain their
+//   atomics, release fence, ticket; the last arriver acquires) scans the bins from the top, finds the threshold score and how many of its ties
+//   are taken, and zeroes the bins again.  Small blocks (256 threads, no LDS to speak of): in the pipeline this chain runs on a side stream beside
+//   the flash kernel, whose two blocks per CU leave only a register / LDS remainder.
+// k_tome_maps2: one thread per src / dst token.  A src block needs the number of ties / lower scores BEFORE its first token: it simply counts them
+//   over the preceding keys (<= 64 k keys of 8 B, L2-resident: 3.6 M key reads in total at na = 43 200 -- less than one pass of the score kernel's
+//   epilogue), in-block prefixes by ballot / popcount.  The last block to finish clears the key array for the next match (last-arriver ticket
+//   again), so the workspace is all-zero between matches except the two result words at a fixed offset -- rounds 2-3 left per-chunk scan words
+//   behind the keys, which a later match with a LARGER src count then met as initial keys (harmless in practice: they sat below any real
+//   threshold; gone now).
 #define THR_BS 256
-__global__ __launch_bounds__(THR_BS) void k_thr_hist(const unsigned long long* __restrict__ keys, int na, int level, const int* __restrict__ sel,
-                                                     int* __restrict__ hist) {
-    __shared__ int h[256];
+#define THR_CTRL_INTS 8      // ws ints [768, 776): ticket of k_thr_select, ticket of k_tome_maps2, thr, take
+__global__ __launch_bounds__(THR_BS) void k_thr_select(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ hist16, int* __restrict__ ctrl) {
+    __shared__ int sc[THR_BS];
+    __shared__ int s_last, s_who;
     const int tid = threadIdx.x;
-    h[tid] = 0;
+    for (int i = blockIdx.x * THR_BS + tid; i < na; i += gridDim.x * THR_BS)
+        __hip_atomic_fetch_add(hist16 + (int)((keys[i] >> 32) & 0xFFFFu), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int bucket = level ? sel[0] : 0;
-    for (int i = blockIdx.x * THR_BS + tid; i < na; i += gridDim.x * THR_BS) {
-        const unsigned sc = (unsigned)((keys[i] >> 32) & 0xFFFFu);
-        if (!level) atomicAdd(&h[sc >> 8], 1);
-        else if ((int)(sc >> 8) == bucket) atomicAdd(&h[sc & 255u], 1);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(ctrl + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_who = -1;
     }
     __syncthreads();
-    if (h[tid]) atomicAdd(hist + level * 256 + tid, h[tid]);
+    if (!s_last) return;
+    // thread t owns the 256 bins [65535 - 256 t - 255, 65535 - 256 t]: descending score order over t
+    const int hi = 65535 - 256 * tid;
+    int cnt = 0;
+    for (int q = 0; q < 256; ++q) cnt += __hip_atomic_load(hist16 + hi - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sc[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < THR_BS; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
+    const int incl = sc[tid], excl = incl - cnt;
+    if (r > 0 && excl < r && r <= incl) s_who = tid;
+    __syncthreads();
+    if (r <= 0) { if (tid == 0) { ctrl[2] = 0x10000; ctrl[3] = 0; } }        // nothing merged
+    else if (tid == s_who) {
+        int above = excl, thr = hi;
+        for (int q = 0; q < 256; ++q) {
+            const int c = __hip_atomic_load(hist16 + hi - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (above + c >= r) { thr = hi - q; break; }
+            above += c;
+        }
+        ctrl[2] = thr; ctrl[3] = r - above;                                   // threshold score; ties taken (lowest src index first)
+    }
+    __syncthreads();
+    for (int q = 0; q < 256; ++q) hist16[hi - q] = 0;                         // bins back to zero for the next match
+    if (tid == 0) ctrl[0] = 0;
 }
-// suffix sums from the top bin: bucket b with count(bins > b) < need <= count(bins >= b); sel[0] = b, sel[1] = need - count(bins > b)
-__device__ __forceinline__ void thr_pick(const int* __restrict__ hist, int need, int* bucket, int* rest, int* sc /* LDS, 256 */) {
-    const int tid = threadIdx.x;
-    sc[tid] = hist[255 - tid];                          // descending bin order
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = tid >= off ? sc[tid - off] : 0;
-        __syncthreads();
-        sc[tid] += v;
-        __syncthreads();
-    }
-    const int incl = sc[tid], excl = incl - hist[255 - tid];
-    if (excl < need && need <= incl) { *bucket = 255 - tid; *rest = need - excl; }
-    __syncthreads();
-}
-__global__ __launch_bounds__(THR_BS) void k_thr_pick1(int* __restrict__ hist, int r, int* __restrict__ sel) {
-    __shared__ int sc[256];
-    __shared__ int b, rest;
-    if (threadIdx.x == 0) { b = 0; rest = 0; }
-    __syncthreads();
-    if (r > 0) thr_pick(hist, r, &b, &rest, sc);
-    __syncthreads();
-    if (threadIdx.x == 0) { sel[0] = b; sel[1] = rest; }
-    hist[threadIdx.x] = 0;                              // level-0 histogram consumed: leave it zero for the next match
-}
-template <int PER>
-__global__ __launch_bounds__(THR_BS) void k_thr_final(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ hist, const int* __restrict__ sel,
-                                                      int* __restrict__ aux) {
-    __shared__ int sc[256];
-    __shared__ int ctie[1024], clow[1024];
-    __shared__ int b2, take_s;
-    const int tid = threadIdx.x;
-    if (tid == 0) { b2 = 0; take_s = 0; }
-    for (int c = tid; c < 1024; c += THR_BS) { ctie[c] = 0; clow[c] = 0; }
-    __syncthreads();
-    int thr = 0x10000, take = 0;                        // r == 0: nothing merged
-    if (r > 0) {
-        thr_pick(hist + 256, sel[1], &b2, &take_s, sc);
-        thr = (sel[0] << 8) | b2; take = take_s;
-    }
-    hist[256 + tid] = 0;
-    // per-chunk counts of ties / lower scores (chunk = PER consecutive src indices), then exclusive scans over the 1024 chunks
-    for (int i = tid; i < na; i += THR_BS) {
-        const int s16 = (int)((keys[i] >> 32) & 0xFFFFu);
-        if (s16 == thr) atomicAdd(&ctie[i / PER], 1);
-        else if (s16 < thr) atomicAdd(&clow[i / PER], 1);
-    }
-    __syncthreads();
-    // 4 consecutive chunks per thread: local exclusive prefix + block scan of the thread totals
-    int t4[4], l4[4], tt = 0, ll = 0;
+#define TOME_MAPS_BS 256
+__device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { t4[q] = tt; l4[q] = ll; tt += ctie[tid * 4 + q]; ll += clow[tid * 4 + q]; }
-    __syncthreads();
-    sc[tid] = tt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
-    const int tbase = sc[tid] - tt;
-    __syncthreads();
-    sc[tid] = ll;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
-    const int lbase = sc[tid] - ll;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { aux[2 + 2 * (tid * 4 + q)] = tbase + t4[q]; aux[3 + 2 * (tid * 4 + q)] = lbase + l4[q]; }
-    if (tid == 0) { aux[0] = thr; aux[1] = take; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
-// pass 2 (grid): maps, one thread per src / dst token.  Blocks of 192 threads (a multiple of every PER) own whole PER-chunks of src
-// tokens: the scores of the block are staged in LDS for the in-chunk tie / lower counts, and once the block has read them each
-// thread clears its own key, so the next match needs no memset and no extra launch.  Blocks >= nsb map the dst tokens.
-#define TOME_MAPS_BS 192
-__global__ __launch_bounds__(TOME_MAPS_BS) void k_tome_maps(unsigned long long* __restrict__ keys, const int* __restrict__ aux, int per, int na, int nb,
-                                                            int r, int nsb, const int* __restrict__ a_pos, const int* __restrict__ b_pos,
-                                                            int* __restrict__ mrg, int* __restrict__ unm) {
-    __shared__ unsigned short ssc[TOME_MAPS_BS];
-    const int nun = na - r, tid = threadIdx.x;
+__global__ __launch_bounds__(TOME_MAPS_BS) void k_tome_maps2(unsigned long long* __restrict__ keys, int* __restrict__ ctrl, int na, int nb, int r, int nsb,
+                                                             const int* __restrict__ a_pos, const int* __restrict__ b_pos, int* __restrict__ mrg,
+                                                             int* __restrict__ unm) {
+    __shared__ int s_bt[4], s_bl[4], s_ct[4], s_cl[4], s_last;
+    const int nun = na - r, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int thr = ctrl[2], take = ctrl[3];
     if ((int)blockIdx.x >= nsb) {
         const int j = ((int)blockIdx.x - nsb) * TOME_MAPS_BS + tid;
         if (j < nb) { const int pos = b_pos[j]; mrg[nun + j] = pos; unm[pos] = nun + j; }
-        return;
-    }
-    const int i = blockIdx.x * TOME_MAPS_BS + tid;
-    const unsigned long long k = i < na ? keys[i] : 0ull;
-    const int sc = (int)((k >> 32) & 0xFFFFu);
-    ssc[tid] = (unsigned short)sc;
-    __syncthreads();
-    if (i >= na) return;
-    keys[i] = 0ull;
-    const int thr = aux[0], take = aux[1], c = i / per, t0 = tid - (i - c * per);
-    int tie_before = aux[2 + 2 * c], low_before = aux[3 + 2 * c];
-    for (int q = t0; q < tid; ++q) { const int sq = ssc[q]; tie_before += sq == thr; low_before += sq < thr; }
-    const int pos = a_pos[i];
-    const bool merged = sc > thr || (sc == thr && tie_before < take);
-    if (merged) {
-        const unsigned cidx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-        unm[pos] = nun + (int)(cidx % (unsigned)nb);
     } else {
-        // unmerged slot = number of unmerged src tokens before i = (#lower before) + (#ties before that were not taken)
-        const int slot = low_before + max(tie_before - take, 0);
-        mrg[slot] = pos; unm[pos] = slot;
+        const int i0 = blockIdx.x * TOME_MAPS_BS, i = i0 + tid;
+        int tb = 0, lb = 0;                                                   // ties / lower scores among the src tokens before this block
+        for (int q = tid; q < i0; q += TOME_MAPS_BS) {
+            const int s16 = (int)((keys[q] >> 32) & 0xFFFFu);
+            tb += s16 == thr; lb += s16 < thr;
+        }
+        tb = wave_sum_i(tb); lb = wave_sum_i(lb);
+        const unsigned long long k = i < na ? keys[i] : 0ull;
+        const int sc = (int)((k >> 32) & 0xFFFFu);
+        const unsigned long long mt = __ballot(i < na && sc == thr), ml = __ballot(i < na && sc < thr), below = (1ull << lane) - 1ull;
+        if (lane == 0) { s_bt[wid] = tb; s_bl[wid] = lb; s_ct[wid] = __popcll(mt); s_cl[wid] = __popcll(ml); }
+        __syncthreads();
+        int tie_before = __popcll(mt & below), low_before = __popcll(ml & below);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { tie_before += s_bt[w] + (w < wid ? s_ct[w] : 0); low_before += s_bl[w] + (w < wid ? s_cl[w] : 0); }
+        if (i < na) {
+            const int pos = a_pos[i];
+            const bool merged = sc > thr || (sc == thr && tie_before < take);
+            if (merged) {
+                const unsigned cidx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+                unm[pos] = nun + (int)(cidx % (unsigned)nb);
+            } else {
+                // unmerged slot = number of unmerged src tokens before i = (#lower before) + (#ties before that were not taken)
+                const int slot = low_before + max(tie_before - take, 0);
+                mrg[slot] = pos; unm[pos] = slot;
+            }
+        }
     }
+    // every block is done READING keys once its loads have returned; the last one to say so clears them for the next match
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(ctrl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int q = tid; q < na; q += TOME_MAPS_BS) keys[q] = 0ull;
+    if (tid == 0) ctrl[1] = 0;
 }
 // out[i] = outer[off + inner[i]]  (inner NULL = identity)
 __global__ void k_index_compose(const int* __restrict__ outer, const int* __restrict__ inner, int off, int n, int* __restrict__ out) {
@@ -475,7 +459,7 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
     TCL_LAUNCH_RET();
 }
 
-size_t tcl_tome_match_workspace_bytes(int na) { return 4096 + ((size_t)na * 8 + 255) / 256 * 256 + (2 + 2 * 1024) * 4 + 1024; }
+size_t tcl_tome_match_workspace_bytes(int na) { return 4096 + 65536 * 4 + ((size_t)na * 8 + 255) / 256 * 256 + 1024; }
 
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
@@ -487,9 +471,12 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     // ws: [histograms 512 ints + 2 selector words | keys na x 8 B | aux]; histograms and keys are all-zero on entry (the caller zeroes the
     // workspace once) and are left all-zero -- the histograms sit at a FIXED offset so that a workspace re-used for a different na never
     // maps them onto a previous call's (non-zero) aux words
-    int* hist = (int*)ws;
-    int* sel = hist + 512;
-    unsigned long long* keys = (unsigned long long*)((char*)ws + 4096);
+    // ws: [4 KiB control: ints 768.. = tickets, thr, take | 65 536 histogram bins | keys na x 8 B]; bins, tickets and keys are all-zero on entry
+    // (the caller zeroes the workspace once) and are left all-zero; every region sits at a fixed offset or behind everything else, so a
+    // workspace re-used for another na never shows a match a previous match's scratch
+    int* ctrl = (int*)ws + 768;
+    int* hist16 = (int*)((char*)ws + 4096);
+    unsigned long long* keys = (unsigned long long*)((char*)ws + 4096 + 65536 * 4);
     const int ts = cdiv(na, 128), td = cdiv(nb, 128);
     const size_t lds = (size_t)3 * 256 * 64, lds320 = (size_t)4 * 128 * 128;
     static bool set = false;
@@ -522,17 +509,10 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
                        spb, keys);
     }
-    int* aux = (int*)((char*)ws + 4096 + ((size_t)na * 8 + 255) / 256 * 256);
-    const int per = na <= 8 * 1024 ? 8 : (na <= 24 * 1024 ? 24 : 64);
     const int hg = na >= 16384 ? 64 : (na >= 2048 ? 16 : 2);
-    hipLaunchKernelGGL(k_thr_hist, dim3(hg), dim3(THR_BS), 0, st, keys, na, 0, sel, hist);
-    hipLaunchKernelGGL(k_thr_pick1, dim3(1), dim3(THR_BS), 0, st, hist, r, sel);
-    hipLaunchKernelGGL(k_thr_hist, dim3(hg), dim3(THR_BS), 0, st, keys, na, 1, sel, hist);
-    if (per == 8) hipLaunchKernelGGL(k_thr_final<8>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
-    else if (per == 24) hipLaunchKernelGGL(k_thr_final<24>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
-    else hipLaunchKernelGGL(k_thr_final<64>, dim3(1), dim3(THR_BS), 0, st, keys, na, r, hist, sel, aux);
+    hipLaunchKernelGGL(k_thr_select, dim3(hg), dim3(THR_BS), 0, st, keys, na, r, hist16, ctrl);
     const int nsb = cdiv(na, TOME_MAPS_BS);
-    hipLaunchKernelGGL(k_tome_maps, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, aux, per, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
+    hipLaunchKernelGGL(k_tome_maps2, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, ctrl, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();
 }
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,

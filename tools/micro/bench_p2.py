@@ -22,7 +22,7 @@ inv, K = ids.reshape(-1).to(torch.int32), last
 rng = np.random.default_rng(0)
 sched = P.make_schedule(n, 16, -(-iters // -(-n // 16)), rng)[:iters]
 b, Pp = 16, h * w
-for stage in (1, 2):
+for stage in [int(v) for v in os.environ.get('P2_STAGES', '1,2').split(',')]:        # P2_STAGES=2: stage 2 only (traffic passes)
     ds = P.OptDataset(ed, flows, masks, device="cuda")
     f = (lambda: P.exposure_align(ds, sched, epochs=1, batch_size=16)) if stage == 1 else (lambda: P.unique_tensor_optimization(ds, inv, sched, batch_size=16, k=K))
     f(); torch.cuda.synchronize(); ds = P.OptDataset(ed, flows, masks, device="cuda")

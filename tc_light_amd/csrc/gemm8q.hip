@@ -45,7 +45,7 @@ typedef float q_float4 __attribute__((ext_vector_type(4)));
 
 #define Q_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int WM, int WN, int RI, int CJ, bool CONV>
+template <int WM, int WN, int RI, int CJ, bool CONV, bool UPS = false>
 __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const _Float16* __restrict__ bias,
                                                 const _Float16* __restrict__ resid, _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw,
                                                 int ldc, int ldr, int act, ConvP cp, int tiles_m, int tiles_n, unsigned a_bytes, unsigned w_bytes) {
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
     const int srow = tid >> 3;
     const unsigned csrc = (unsigned)(((tid & 7) ^ ((srow >> 1) & 7)) * 16);
     unsigned aoff[NA][2]; unsigned amask[NA];                    // [pass][half]; conv: per pass 2 x 9 tap bits
+    unsigned aw[UPS ? NA : 1][2];                                // UPS: per (pass, half) 9 tap bits | 3 x 2-bit source-row deltas | 3 x 2-bit source-column deltas
 #pragma unroll
     for (int p = 0; p < NA; ++p) amask[p] = 0u;
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
         for (int h = 0; h < 2; ++h) {
             const int R = 64 * p + srow, m = m0 + (R / QM) * (2 * QM) + h * QM + R % QM;
             if (!CONV) aoff[p][h] = (unsigned)min(m, M - 1) * (unsigned)lda * 2u + csrc;
-            else {
+            else if (!UPS) {
                 const int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
                 const int iy0 = oy * cp.stride - cp.pad, ix0 = ox * cp.stride - cp.pad;
                 aoff[p][h] = (unsigned)(((b * cp.Hin + iy0) * cp.Win + ix0) * cp.Cin) * 2u + csrc;      // wraps for border pixels; only used with a valid tap
@@ -99,6 +100,24 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
                     if (m < M && iy >= 0 && iy < cp.Hin && ix >= 0 && ix < cp.Win) mk |= 1u << tap;
                 }
                 amask[p] |= mk << (9 * h);
+            } else {
+                // nearest up-sampling fused in the gather (stride 1, pad 1; UNet up-samplers, scale Hin / Hup in (0.5, 1]): the three logical rows
+                // oy - 1 .. oy + 1 of the up-sampled image map to source rows base, base + {0,1}, base + {0,1,2} (k_gemm8s's own formula:
+                // min(floor(y * sy), Hin - 1)); the per-lane word keeps those deltas, the tap picks one (2 bit-field extracts + 2 mads per piece)
+                const int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
+                auto sy_ = [&](int y) { return min((int)floorf(min(max(y, 0), cp.Hup - 1) * cp.sy), cp.Hin - 1); };
+                auto sx_ = [&](int x) { return min((int)floorf(min(max(x, 0), cp.Wup - 1) * cp.sx), cp.Win - 1); };
+                const int by = sy_(oy - 1), bx = sx_(ox - 1);
+                aoff[p][h] = (unsigned)(((b * cp.Hin + by) * cp.Win + bx) * cp.Cin) * 2u + csrc;
+                unsigned wd = 0;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+                    if (m < M && iy >= 0 && iy < cp.Hup && ix >= 0 && ix < cp.Wup) wd |= 1u << tap;
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { wd |= (unsigned)(sy_(oy - 1 + d) - by) << (9 + 2 * d); wd |= (unsigned)(sx_(ox - 1 + d) - bx) << (15 + 2 * d); }
+                aw[p][h] = wd;
             }
         }
     unsigned woff[NB];                                          // [pass]; half g adds QN rows (scalar)
@@ -128,11 +147,16 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
     const int nt = K / 64;
 
     // scalars of the K tile being staged (conv: tap + channel slice -> input offset / weight column); SC_(U) is called once per tile
-    unsigned s_ka = 0, s_kw = 0; int s_tap = 0;
+    unsigned s_ka = 0, s_kw = 0; int s_tap = 0, s_shy = 9, s_shx = 15;
+    const unsigned c2_ = (unsigned)cp.Cin * 2u, wc2_ = (unsigned)cp.Win * c2_;
 #define Q_SCAL(U)                                                                                                             \
     {                                                                                                                         \
         int ka_ = (U) * 64, kw_ = ka_; s_tap = 0;                                                                             \
-        if (CONV) { int c0_; s_tap = conv_kmap(ka_, cp.Cin, c0_); kw_ = s_tap * cp.Cin + c0_; ka_ = ((s_tap / 3) * cp.Win + s_tap % 3) * cp.Cin + c0_; } \
+        if (CONV) {                                                                                                           \
+            int c0_; s_tap = conv_kmap(ka_, cp.Cin, c0_); kw_ = s_tap * cp.Cin + c0_;                                         \
+            if (UPS) { ka_ = c0_; s_shy = 9 + 2 * (s_tap / 3); s_shx = 15 + 2 * (s_tap % 3); }                                \
+            else ka_ = ((s_tap / 3) * cp.Win + s_tap % 3) * cp.Cin + c0_;                                                     \
+        }                                                                                                                     \
         s_ka = (unsigned)ka_ * 2u; s_kw = (unsigned)kw_ * 2u;                                                                 \
     }
     // one half-tile of tile U (scalars already set) into buffer U & 1
@@ -141,9 +165,13 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
         char* d_ = sdst + ((U) & 1) * BUF + (H) * A_HALF;                                                                     \
         _Pragma("unroll") for (int p_ = 0; p_ < NA; ++p_) {                                                                  \
             if (!CONV) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, Q_LDS(d_ + p_ * 8192), 16, aoff[p_][H], s_ka, 0, 0);      \
-            else {                                                                                                            \
+            else if (!UPS) {                                                                                                  \
                 const unsigned vo_ = ((amask[p_] >> (9 * (H) + s_tap)) & 1u) ? aoff[p_][H] + s_ka : 0xffffffffu;       \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, Q_LDS(d_ + p_ * 8192), 16, vo_, 0, 0, 0);                        \
+            } else {                                                                                                          \
+                const unsigned w_ = aw[UPS ? p_ : 0][H];                                                                      \
+                const unsigned o_ = aoff[p_][H] + ((w_ >> s_shy) & 3u) * wc2_ + ((w_ >> s_shx) & 3u) * c2_ + s_ka;            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, Q_LDS(d_ + p_ * 8192), 16, ((w_ >> s_tap) & 1u) ? o_ : 0xffffffffu, 0, 0, 0); \
             }                                                                                                                 \
         }                                                                                                                     \
     }
@@ -342,18 +370,20 @@ static int launch8q(const _Float16* A, const _Float16* W, const _Float16* bias, 
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_gemm8q<WM, WN, RI, CJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k_gemm8q<WM, WN, RI, CJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gemm8q<WM, WN, RI, CJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const size_t a_bytes = cp.conv ? (size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 : ((size_t)(M - 1) * lda + K) * 2;
     const size_t w_bytes = ((size_t)(N - 1) * ldw + K) * 2;
-    if (cp.conv) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
+    if (cp.conv && (cp.Hup != cp.Hin || cp.Wup != cp.Win)) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
+    else if (cp.conv) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
     else hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, false>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
 // Can the 8-phase kernel take this call?  cfg 1 = 256 x 256 (N % 256 == 0; GEGLU allowed), 2 = 256 x 320 (N % 320 == 0), 3 = 512 x 128 (N % 128 == 0:
 // the VAE's 128-channel convolutions at full resolution; WM 8, WN 1, quadrant 32 x 64, all 160 KiB of LDS).  K % 64 == 0 (conv:
-// Cin % 64 == 0), operands addressable with 32 bits, no nearest-upsampling gather (those convolutions stay on k_gemm8s), 16-B aligned rows.
+// Cin % 64 == 0), operands addressable with 32 bits, nearest up-sampling only by a factor <= 2 per axis (stride 1, pad 1), 16-B aligned rows.
 bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
     const int BN = cfg == 1 ? 256 : (cfg == 2 ? 320 : 128);
     if (N % BN || K % 64 || K < 64 || M < 1) return false;
@@ -361,7 +391,10 @@ bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
     if (act == 2 && (cfg != 1 || has_resid)) return false;
     if (act < 0 || act > 5) return false;
     if (cp.conv) {
-        if (cp.Cin % 64 || cp.Hup != cp.Hin || cp.Wup != cp.Win) return false;
+        if (cp.Cin % 64) return false;
+        if (cp.Hup != cp.Hin || cp.Wup != cp.Win) {      // nearest up-sampling in the gather: stride 1, pad 1, scale in (0.5, 1] per axis (source-row deltas 0..2)
+            if (cp.stride != 1 || cp.pad != 1 || cp.Hup < cp.Hin || cp.Wup < cp.Win || cp.Hup > 2 * cp.Hin || cp.Wup > 2 * cp.Win) return false;
+        }
         if ((size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 >= 0xffffff00ull) return false;
     } else {
         if ((lda & 7) || ((size_t)(M - 1) * lda + K) * 2 >= 0xffffff00ull) return false;

@@ -399,12 +399,14 @@ def test_gemm_configs_bit_identical(L, shape):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", ["silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "conv_s2", "conv_s2_pad0", "conv_silu_resid", "n128_silu_resid", "conv_n128_s2_pad0"])
+@pytest.mark.parametrize("case", ["silu", "gelu_after_resid", "k64", "k128", "k320_small_m", "geglu", "conv_s2", "conv_s2_pad0", "conv_silu_resid", "n128_silu_resid", "conv_n128_s2_pad0",
+                                  "conv_up_23x40", "conv_up_2x", "conv_up_one_axis"])
 def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
     """The 8-phase kernels (cfg 13 = 256x256, 14 = 256x320, 15 = 512x128; csrc/gemm8q.hip) against the LDS-DMA tile kernel (cfg 1) and the round-3 8-wave
     kernel (cfg 7, GEGLU) on what test_gemm_configs_bit_identical does not reach: every epilogue (SiLU, GELU after the residual, GEGLU in
     registers), K = one / two / five K tiles (prologue and tail paths of the two-buffer ring), fewer rows than one tile, stride-2 convolutions
-    with symmetric and with the VAE encoder's asymmetric padding (tap masks), a convolution with activation + residual.  Bit equality."""
+    with symmetric and with the VAE encoder's asymmetric padding (tap masks), a convolution with activation + residual, nearest up-sampling
+    fused in the gather (12x20 -> 23x40: not a factor 2; exact 2x; one axis only, as the yt planes of short windows produce).  Bit equality."""
     g = torch.Generator(device="cuda").manual_seed(11)
     mk = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(H)
     ref_cfg = 1
@@ -424,17 +426,21 @@ def test_gemm8q_epilogues_and_tails_equal_tiled_kernels(L, case):
             return C
         cfgs = (13,) if act == 2 else ((15,) if N == 128 else (13, 14))
     else:
-        B, Hh, Ww, Ci, Co, stride, pad, act, hasr = {"conv_s2": (3, 46, 30, 640, 640, 2, 1, 0, False), "conv_s2_pad0": (2, 40, 56, 256, 256, 2, 0, 0, False),
+        up = {"conv_up_23x40": (23, 40), "conv_up_2x": (20, 32), "conv_up_one_axis": (3, 12)}.get(case)
+        B, Hh, Ww, Ci, Co, stride, pad, act, hasr = {"conv_s2": (3, 46, 30, 640, 640, 2, 1, 0, False),
+                                                     "conv_up_23x40": (3, 12, 20, 640, 1280, 1, 1, 0, False), "conv_up_2x": (2, 10, 16, 256, 256, 1, 1, 0, True),
+                                                     "conv_up_one_axis": (40, 3, 6, 640, 640, 1, 1, 0, False), "conv_s2_pad0": (2, 40, 56, 256, 256, 2, 0, 0, False),
                                                      "conv_silu_resid": (5, 23, 30, 320, 640, 1, 1, 1, True),
                                                      "conv_n128_s2_pad0": (2, 44, 60, 128, 128, 2, 0, 0, False)}[case]
-        Ho = (Hh + 2 - 3) // stride + 1 if pad else (Hh + 1 - 3) // stride + 1
-        Wo = (Ww + 2 - 3) // stride + 1 if pad else (Ww + 1 - 3) // stride + 1
+        Hu, Wu = up if up else (Hh, Ww)
+        Ho = (Hu + 2 - 3) // stride + 1 if pad else (Hu + 1 - 3) // stride + 1
+        Wo = (Wu + 2 - 3) // stride + 1 if pad else (Wu + 1 - 3) // stride + 1
         x, w, b = mk(B, Hh, Ww, Ci), mk(Co, 9 * Ci, sc=(9 * Ci) ** -0.5), mk(Co)
         R = mk(B, Ho, Wo, Co) if hasr else None
 
         def run():
             y = torch.empty(B, Ho, Wo, Co, device="cuda", dtype=H)
-            L.tcl_conv3x3_f16(x, w, b, R if hasr else 0, y, B, Hh, Ww, Ci, Co, stride, pad, 0, 0, act, st())
+            L.tcl_conv3x3_f16(x, w, b, R if hasr else 0, y, B, Hh, Ww, Ci, Co, stride, pad, up[0] if up else 0, up[1] if up else 0, act, st())
             return y
         cfgs = (13, 14) if Co % 1280 == 0 else ((13,) if Co % 256 == 0 else (14,))
         if Co == 640:

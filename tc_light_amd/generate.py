@@ -36,7 +36,7 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
                                      #   from K ~ 1e7 up; kept for memory-bound cases).  "shard": the round-1 approximation, each rank's frame
                                      #   block as a video of its own (tracks cut at the block seams) -- NOT the reference's result.
     shard_post_opt=False,            # legacy spelling of post_opt_mode="shard"
-    max_tokens_per_pass=1_500_000)   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split
+    max_tokens_per_pass=int(__import__("os").environ.get("TCL_MAX_TOKENS_PER_PASS", 1_500_000)))   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split
 
 
 class Generator:

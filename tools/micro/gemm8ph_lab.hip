@@ -38,7 +38,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 // SWZ 0: st_16x32 as the guide writes it (chunk ^= ((row >> 2) & 1) << 1: 4-way instead of 8-way conflicts); 1: chunk ^= (row >> 1) & 7 (conflict-free
 // for 16 consecutive rows of 128 B)
-template <int SWZ, int PRIO>
+template <int SWZ, int PRIO, int GM = 1>
 __global__ __launch_bounds__(512) void k_g8ph(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ C, int M, int N, int K,
                                               int lda, int ldw, int ldc, int tiles_m, int tiles_n, unsigned a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(512) void k_g8ph(const _Float16* __restrict__ A, co
     // bijective XCD remap (guide, "XCD swizzle must be bijective")
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    // GM > 1: an XCD's run of tiles walks GM-row bands column by column (its 32 concurrent tiles share GM A panels and 32 / GM B panels)
+    const int tm = GM > 1 ? (wg / (GM * tiles_n)) * GM + (wg % (GM * tiles_n)) % GM : wg / tiles_n, tn = GM > 1 ? (wg % (GM * tiles_n)) / GM : wg % tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
 
@@ -210,12 +211,12 @@ __global__ void k_maxdiff(const _Float16* a, const _Float16* b, size_t n, unsign
     atomicMax(out, __float_as_uint(mx));
 }
 
-template <int SWZ, int PRIO>
+template <int SWZ, int PRIO, int GM = 1>
 static void run_ph(const _Float16* A, const _Float16* W, _Float16* C, int M, int N, int K, hipStream_t st) {
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute((const void*)k_g8ph<SWZ, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); set = true; }
+    if (!set) { CK(hipFuncSetAttribute((const void*)k_g8ph<SWZ, PRIO, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); set = true; }
     const int tm = M / 256, tn = N / 256;
-    hipLaunchKernelGGL((k_g8ph<SWZ, PRIO>), dim3(tm * tn), dim3(512), 131072, st, A, W, C, M, N, K, K, K, N, tm, tn, (unsigned)((size_t)M * K * 2), (unsigned)((size_t)N * K * 2));
+    hipLaunchKernelGGL((k_g8ph<SWZ, PRIO, GM>), dim3(tm * tn), dim3(512), 131072, st, A, W, C, M, N, K, K, K, N, tm, tn, (unsigned)((size_t)M * K * 2), (unsigned)((size_t)N * K * 2));
 }
 
 int main(int argc, char** argv) {
@@ -239,16 +240,19 @@ int main(int argc, char** argv) {
         ConvP cp = {};
         // variants: 0 = k_gemm8 256x256 (round-2 ping-pong), 1 = k_gemm8p 256x256 (product default), 2 = 8-phase st_16x32 + setprio (as written),
         //           3 = 8-phase st_16x32 without setprio, 4 = 8-phase with the conflict-free swizzle + setprio
-        const char* names[5] = {"k_gemm8  256x256 (r2 ping-pong)", "k_gemm8p 256x256 (product)", "8-phase st_16x32 setprio (guide)", "8-phase st_16x32 no setprio", "8-phase full swizzle setprio"};
+        const char* names[7] = {"k_gemm8  256x256 (r2 ping-pong)", "k_gemm8p 256x256 (product)", "8-phase st_16x32 setprio (guide)", "8-phase st_16x32 no setprio", "8-phase full swizzle setprio", "8-phase st_16x32, 4-row bands", "8-phase st_16x32, 8-row bands"};
         auto launch = [&](int v, _Float16* C) {
             if (v == 0) { g_gemm8_sched = 0; gemm8_dispatch(3, A, W, nullptr, nullptr, C, M, N, K, K, K, N, N, 0, cp, st); }
             else if (v == 1) { g_gemm8_sched = 2; gemm8_dispatch(3, A, W, nullptr, nullptr, C, M, N, K, K, K, N, N, 0, cp, st); }
             else if (v == 2) run_ph<0, 1>(A, W, C, M, N, K, st);
             else if (v == 3) run_ph<0, 0>(A, W, C, M, N, K, st);
-            else run_ph<1, 1>(A, W, C, M, N, K, st);
+            else if (v == 4) run_ph<1, 1>(A, W, C, M, N, K, st);
+            else if (v == 5) run_ph<0, 0, 4>(A, W, C, M, N, K, st);
+            else run_ph<0, 0, 8>(A, W, C, M, N, K, st);
         };
-        std::vector<float> tms[5];
-        for (int v = 0; v < 5; ++v) {
+        const int NV = (M / 256) % 8 == 0 ? 7 : 5;
+        std::vector<float> tms[7];
+        for (int v = 0; v < NV; ++v) {
             _Float16* C = v == 1 ? C0 : C1;
             CK(hipMemsetAsync(C, 0xff, (size_t)M * N * 2, st));
             launch(v, C);
@@ -270,14 +274,14 @@ int main(int argc, char** argv) {
             printf("   check %-34s max rel err vs f32 reference (8192 samples) %.2e%s\n", names[v], mx, v >= 2 ? (std::string("   max |x - product| / (|product| + 1) over all outputs, 3 launches: ") + std::to_string(mdf)).c_str() : "");
         }
         for (int round = 0; round < 7; ++round)
-            for (int v = 0; v < 5; ++v) {
+            for (int v = 0; v < NV; ++v) {
                 CK(hipEventRecord(e0, st));
                 for (int r = 0; r < 4; ++r) launch(v, C1);
                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 tms[v].push_back(ms / 4);
             }
-        for (int v = 0; v < 5; ++v) {
+        for (int v = 0; v < NV; ++v) {
             std::sort(tms[v].begin(), tms[v].end());
             printf("   %-34s median %8.1f us  %6.0f TFLOP/s   (best %6.0f)\n", names[v], tms[v][3] * 1e3, flop / tms[v][3] / 1e9, flop / tms[v][0] / 1e9);
         }

@@ -48,7 +48,7 @@ typedef float q_float4 __attribute__((ext_vector_type(4)));
 template <int WM, int WN, int RI, int CJ, bool CONV, bool UPS = false>
 __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, const _Float16* __restrict__ W, const _Float16* __restrict__ bias,
                                                 const _Float16* __restrict__ resid, _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw,
-                                                int ldc, int ldr, int act, ConvP cp, int tiles_m, int tiles_n, unsigned a_bytes, unsigned w_bytes) {
+                                                int ldc, int ldr, int act, ConvP cp, int tiles_m, int tiles_n, unsigned long a_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(WM * WN == 8, "8 waves");
     constexpr int QM = RI * 16, QN = CJ * 16, BM = 2 * WM * QM, BN = 2 * WN * QN;
@@ -74,7 +74,12 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
     const int wr = wid / WN, wc = wid % WN;                     // wr-half 0 = waves 0-3, 1 = waves 4-7 (the two waves of a SIMD)
     const int grp = wid >> 2;
 
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    // A is addressed RELATIVE to the block's first row (dense) / first image (conv): the 32-bit per-lane offsets then span one tile (<= 3 images),
+    // whatever the size of the whole operand (block-major passes carry > 4 GiB activations: 3.5 M rows x 1280 channels)
+    const int b0_ = CONV ? m0 / (cp.Hout * cp.Wout) : 0;
+    const unsigned long a_base = CONV ? (unsigned long)b0_ * cp.Hin * cp.Win * cp.Cin * 2ul : (unsigned long)m0 * (unsigned long)lda * 2ul;
+    const unsigned long a_rem = a_bytes - a_base;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A + a_base), 0, (unsigned)(a_rem > 0xffffff00ul ? 0xffffff00ul : a_rem), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, w_bytes, 0x00020000);
     // ---- staging: thread <-> (LDS row R = 64 p + (tid >> 3), chunk' = tid & 7) of a half-tile; source chunk = chunk' ^ ((R >> 1) & 7)
     const int srow = tid >> 3;
@@ -88,11 +93,11 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int R = 64 * p + srow, m = m0 + (R / QM) * (2 * QM) + h * QM + R % QM;
-            if (!CONV) aoff[p][h] = (unsigned)min(m, M - 1) * (unsigned)lda * 2u + csrc;
+            if (!CONV) aoff[p][h] = (unsigned)(min(m, M - 1) - m0) * (unsigned)lda * 2u + csrc;
             else if (!UPS) {
                 const int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
                 const int iy0 = oy * cp.stride - cp.pad, ix0 = ox * cp.stride - cp.pad;
-                aoff[p][h] = (unsigned)(((b * cp.Hin + iy0) * cp.Win + ix0) * cp.Cin) * 2u + csrc;      // wraps for border pixels; only used with a valid tap
+                aoff[p][h] = (unsigned)((((b - b0_) * cp.Hin + iy0) * cp.Win + ix0) * cp.Cin) * 2u + csrc;      // wraps for border pixels; only used with a valid tap
                 unsigned mk = 0;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(512) void k_gemm8q(const _Float16* __restrict__ A, 
                 auto sy_ = [&](int y) { return min((int)floorf(min(max(y, 0), cp.Hup - 1) * cp.sy), cp.Hin - 1); };
                 auto sx_ = [&](int x) { return min((int)floorf(min(max(x, 0), cp.Wup - 1) * cp.sx), cp.Win - 1); };
                 const int by = sy_(oy - 1), bx = sx_(ox - 1);
-                aoff[p][h] = (unsigned)(((b * cp.Hin + by) * cp.Win + bx) * cp.Cin) * 2u + csrc;
+                aoff[p][h] = (unsigned)((((b - b0_) * cp.Hin + by) * cp.Win + bx) * cp.Cin) * 2u + csrc;
                 unsigned wd = 0;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -375,15 +380,15 @@ static int launch8q(const _Float16* A, const _Float16* W, const _Float16* bias, 
     }
     const size_t a_bytes = cp.conv ? (size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 : ((size_t)(M - 1) * lda + K) * 2;
     const size_t w_bytes = ((size_t)(N - 1) * ldw + K) * 2;
-    if (cp.conv && (cp.Hup != cp.Hin || cp.Wup != cp.Win)) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
-    else if (cp.conv) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
-    else hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, false>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned)a_bytes, (unsigned)w_bytes);
+    if (cp.conv && (cp.Hup != cp.Hin || cp.Wup != cp.Win)) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned long)a_bytes, (unsigned)w_bytes);
+    else if (cp.conv) hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, true>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned long)a_bytes, (unsigned)w_bytes);
+    else hipLaunchKernelGGL((k_gemm8q<WM, WN, RI, CJ, false>), dim3(tm * tn), dim3(512), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, tm, tn, (unsigned long)a_bytes, (unsigned)w_bytes);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
 // Can the 8-phase kernel take this call?  cfg 1 = 256 x 256 (N % 256 == 0; GEGLU allowed), 2 = 256 x 320 (N % 320 == 0), 3 = 512 x 128 (N % 128 == 0:
 // the VAE's 128-channel convolutions at full resolution; WM 8, WN 1, quadrant 32 x 64, all 160 KiB of LDS).  K % 64 == 0 (conv:
-// Cin % 64 == 0), operands addressable with 32 bits, nearest up-sampling only by a factor <= 2 per axis (stride 1, pad 1), 16-B aligned rows.
+// Cin % 64 == 0), the weights and one tile's rows of A addressable with 32 bits (A as a whole may be larger), nearest up-sampling only by a factor <= 2 per axis (stride 1, pad 1), 16-B aligned rows.
 bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
     const int BN = cfg == 1 ? 256 : (cfg == 2 ? 320 : 128);
     if (N % BN || K % 64 || K < 64 || M < 1) return false;
@@ -395,9 +400,9 @@ bool gemm8q_ok(int cfg, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
         if (cp.Hup != cp.Hin || cp.Wup != cp.Win) {      // nearest up-sampling in the gather: stride 1, pad 1, scale in (0.5, 1] per axis (source-row deltas 0..2)
             if (cp.stride != 1 || cp.pad != 1 || cp.Hup < cp.Hin || cp.Wup < cp.Win || cp.Hup > 2 * cp.Hin || cp.Wup > 2 * cp.Win) return false;
         }
-        if ((size_t)(M / (cp.Hout * cp.Wout)) * cp.Hin * cp.Win * cp.Cin * 2 >= 0xffffff00ull) return false;
+        if ((size_t)4 * cp.Hin * cp.Win * cp.Cin * 2 >= 0xffffff00ull) return false;      // a tile's rows touch <= 3 consecutive images (addressed relative to the first)
     } else {
-        if ((lda & 7) || ((size_t)(M - 1) * lda + K) * 2 >= 0xffffff00ull) return false;
+        if ((lda & 7) || (size_t)256 * 2 * lda * 2 >= 0xffffff00ull) return false;
     }
     return ((size_t)(N - 1) * ldw + K) * 2 < 0xffffff00ull;
 }

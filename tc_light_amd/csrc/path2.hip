@@ -30,7 +30,10 @@
 typedef long long fx_t;
 #define FX_SSIM 1073741824.f            // 2^30: per-block sums of SSIM values, |.| <= TW*TH
 #define FX_ACC 1048576.f                // 2^20: loss sums over a mini-batch (<= ~1e8)
-#define FX_FLOW 4294967296.f            // 2^32: mask * bicubic weights landing on one pixel of the previous frame
+#define FX_FLOW 4194304.f               // 2^22: mask * bicubic weights landing on one pixel of the previous frame, in a 32-BIT cell (round 4; 2^32 in
+                                        // 64-bit cells before): resolution 2.4e-7 per contribution, range +-512 -- a cell receives ~16 weights of |w| <= 1
+                                        // from a smooth flow; 32-bit integer atomics run ~2x the rate of 64-bit ones and gpre halves (memset, reads)
+typedef int fxq_t;
 #define FX_EXPO 281474976710656.f       // 2^48: exposure gradient components (sums of image * pixel gradient)
 __device__ __forceinline__ void fx_add(fx_t* p, float v, float scale) {
     atomicAdd((unsigned long long*)p, (unsigned long long)__float2ll_rn(v * scale));
@@ -114,7 +117,7 @@ __global__ void k_apply_exposure(const float* __restrict__ src, const int* __res
 // d(loss)/dM of cat row j from the gradient of its clamped output -> efx[j][12] (fixed point; ordered add into grad_expo by k_expo_fin).
 // Rows j >= b are the "previous frame" images: their gradient is the flow term's scatter, held in fixed point (gpre, see k_flow_loss).
 __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ expo,
-                               const float* __restrict__ gimg, const fx_t* __restrict__ gpre, float pre_scale, int b, fx_t* __restrict__ efx, int P) {
+                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, int b, fx_t* __restrict__ efx, int P) {
     __shared__ float red[16];
     const int j = blockIdx.y, f = idx[j];
     const float* M = expo + (size_t)f * 12;
@@ -123,7 +126,7 @@ __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restr
     for (int i = 0; i < 12; ++i) { m[i] = M[i]; acc[i] = 0.f; }
     const float* s = src + (size_t)f * 3 * P;
     const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
-    const fx_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
+    const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         float x[3] = {s[p], s[P + p], s[2 * P + p]};
 #pragma unroll
@@ -162,12 +165,12 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
 // ATOMIC == true (ids that repeat inside a frame): all rows in one launch, float atomics, order not reproducible.
 template <bool ATOMIC>
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                               const float* __restrict__ gimg, const fx_t* __restrict__ gpre, float pre_scale, int b, int j0,
+                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, int b, int j0,
                                float* __restrict__ gfeat, int P, size_t K) {
     const int j = j0 + blockIdx.y, f = fidx[j];
     const int* iv = inv + (size_t)f * P;
     const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
-    const fx_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
+    const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         size_t id = (size_t)iv[p];
 #pragma unroll
@@ -364,7 +367,7 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
 // gpre [b,3,P] in fixed point, UNSCALED (sign * mask * bicubic weight; the consumer multiplies by scale / FX_FLOW): integer atomics.
 // Round 3, second half: the scatter goes through an LDS window.  A block owns a FT_W x FT_H pixel tile; the taps of a smooth flow field land in
 // the tile shifted by the flow plus the bicubic extent, so the block accumulates them in a (FT_W + 3 + slack) x (FT_H + 3 + slack) x 3
-// window of 64-bit LDS cells placed at the minimum tap origin of the tile, and flushes the non-zero cells once: ~5 global atomics per pixel
+// window of integer LDS cells (64-bit in round 3, 32-bit since round 4: FX_FLOW) placed at the minimum tap origin of the tile, and flushes the non-zero cells once: ~5 global atomics per pixel
 // instead of 12, every one of them to consecutive cells of a row.  Taps outside the window (flow discontinuities) go to global memory
 // directly.  Integer sums: the result does not depend on which way an addend took, nor on the order -- and with W % 64 == 0 the waves
 // cover the same 64-pixel row segments as the untiled form (TILED == false, kept for A/B: TCL_FLOW_TILED=0), so the two agree bit for bit.
@@ -373,20 +376,20 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
 #define FT_SL 5
 #define FT_WX (FT_W + 3 + FT_SL)
 #define FT_WY (FT_H + 3 + FT_SL)
-struct FlowWin { unsigned long long* cells; int x0, y0; };
+struct FlowWin { int* cells; int x0, y0; };
 template <bool TILED>
-__device__ __forceinline__ void flow_sink(const FlowWin& w, fx_t* __restrict__ gp, int c, int P, int W, int yy, int xx, float v) {
-    const unsigned long long q = (unsigned long long)__float2ll_rn(v * FX_FLOW);
+__device__ __forceinline__ void flow_sink(const FlowWin& w, fxq_t* __restrict__ gp, int c, int P, int W, int yy, int xx, float v) {
+    const int q = __float2int_rn(v * FX_FLOW);
     if (TILED) {
         const int lx = xx - w.x0, ly = yy - w.y0;
         if ((unsigned)lx < (unsigned)FT_WX && (unsigned)ly < (unsigned)FT_WY) { atomicAdd(w.cells + (c * FT_WY + ly) * FT_WX + lx, q); return; }
     }
-    atomicAdd((unsigned long long*)(gp + (size_t)c * P + (size_t)yy * W + xx), q);
+    atomicAdd(gp + (size_t)c * P + (size_t)yy * W + xx, q);
 }
 // one pixel (x, y) of cat row j: forward term, owner-pixel gradient, scatter of the pre-image gradient.  Returns sum_c |d|.
 template <bool TILED>
 __device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const float* __restrict__ pre, const float* __restrict__ fl,
-                                            const float* __restrict__ mk, float* __restrict__ gi, fx_t* __restrict__ gp, const FlowWin& win,
+                                            const float* __restrict__ mk, float* __restrict__ gi, fxq_t* __restrict__ gp, const FlowWin& win,
                                             int x, int y, bool live, int lane, int H, int W, float scale) {
     const int P = H * W;
     const int pc = live ? y * W + x : P - 1;
@@ -451,14 +454,14 @@ __device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
                                                    const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
-                                                   fx_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x) {
+                                                   fxq_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x) {
     __shared__ float red[16];
     __shared__ int wmin[2];
-    extern __shared__ __attribute__((aligned(16))) unsigned long long fwin[];
+    extern __shared__ __attribute__((aligned(16))) int fwin[];
     const int j = blockIdx.y, f = idx[j], P = H * W;
     if (f == 0) return;  // valid = idx > 0
     const float* img = cat + (size_t)j * 3 * P; const float* pre = cat + (size_t)(b + j) * 3 * P;
-    float* gi = gimg + (size_t)j * 3 * P; fx_t* gp = gpre + (size_t)j * 3 * P;
+    float* gi = gimg + (size_t)j * 3 * P; fxq_t* gp = gpre + (size_t)j * 3 * P;
     const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat
         }
     } else {
         const int X0 = ((int)blockIdx.x % tiles_x) * FT_W, Y0 = ((int)blockIdx.x / tiles_x) * FT_H, wv = threadIdx.x >> 6;
-        for (int i = threadIdx.x; i < 3 * FT_WY * FT_WX; i += 256) fwin[i] = 0ull;
+        for (int i = threadIdx.x; i < 3 * FT_WY * FT_WX; i += 256) fwin[i] = 0;
         if (threadIdx.x < 2) wmin[threadIdx.x] = 0x7fffffff;
         __syncthreads();
         int mx = 0x7fffffff, my = 0x7fffffff;                     // minimum tap origin of the tile's live pixels: the window's corner
@@ -494,10 +497,10 @@ __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat
         }
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * FT_WY * FT_WX; i += 256) {
-            const unsigned long long v = fwin[i];
+            const int v = fwin[i];
             if (v) {
                 const int c = i / (FT_WY * FT_WX), rem = i - c * (FT_WY * FT_WX), ly = rem / FT_WX, lx = rem - ly * FT_WX;
-                atomicAdd((unsigned long long*)(gp + (size_t)c * P + (size_t)(win.y0 + ly) * W + win.x0 + lx), v);
+                atomicAdd(gp + (size_t)c * P + (size_t)(win.y0 + ly) * W + win.x0 + lx, v);
             }
         }
     }
@@ -506,11 +509,11 @@ __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat
 }
 static int g_flow_tiled = -1;
 static void launch_flow_loss(const float* cat, const int* cidx, const float* flows, const float* masks, int b, int H, int W, float fscale, float* gimg,
-                             fx_t* gpre, fx_t* acc, dim3 untiled_grid, hipStream_t st) {
+                             fxq_t* gpre, fx_t* acc, dim3 untiled_grid, hipStream_t st) {
     if (g_flow_tiled < 0) g_flow_tiled = getenv("TCL_FLOW_TILED") ? atoi(getenv("TCL_FLOW_TILED")) : 1;      // A/B hook: 0 = global atomics only
     if (g_flow_tiled) {
         const int tx = cdiv(W, FT_W), ty = cdiv(H, FT_H);
-        hipLaunchKernelGGL(k_flow_loss<true>, dim3(tx * ty, b), dim3(256), (size_t)3 * FT_WY * FT_WX * 8, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, tx);
+        hipLaunchKernelGGL(k_flow_loss<true>, dim3(tx * ty, b), dim3(256), (size_t)3 * FT_WY * FT_WX * 4, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, tx);
     } else hipLaunchKernelGGL(k_flow_loss<false>, untiled_grid, dim3(256), 0, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, 0);
 }
 // loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
@@ -776,12 +779,12 @@ int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float*
 }
 
 // ---- whole-stage drivers -------------------------------------------------------------------
-struct StageWs { float *cat, *gimg; fx_t *gpre, *acc, *efx; int* cidx; MsWs ms; size_t bytes; };
+struct StageWs { float *cat, *gimg; fxq_t* gpre; fx_t *acc, *efx; int* cidx; MsWs ms; size_t bytes; };
 static StageWs carve_stage(char* base, int b, int h, int w) {
     StageWs S; size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
     size_t P = (size_t)h * w;
-    S.cat = (float*)take(2 * b * 3 * P * 4); S.gimg = (float*)take(b * 3 * P * 4); S.gpre = (fx_t*)take(b * 3 * P * sizeof(fx_t));
+    S.cat = (float*)take(2 * b * 3 * P * 4); S.gimg = (float*)take(b * 3 * P * 4); S.gpre = (fxq_t*)take(b * 3 * P * sizeof(fxq_t));
     S.acc = (fx_t*)take(ACC_SLOTS * 4 * sizeof(fx_t)); S.efx = (fx_t*)take((size_t)2 * b * 12 * sizeof(fx_t));
     S.cidx = (int*)take(2 * b * 4);
     size_t msb = carve_ms(nullptr, b * 3, h, w).bytes;
@@ -819,7 +822,7 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
     if (rc) return rc;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, edited, S.cidx, S.ms.gX[1], S.ms.h[1], S.ms.w[1], H, W,
                        c_l1, 0.f, 0.f, S.gimg, S.acc);
-    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fxq_t), st) != hipSuccess) return TCL_ELAUNCH;
     if (hipMemsetAsync(S.efx, 0, (size_t)2 * b * 12 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
@@ -849,7 +852,7 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     float ch = lambda_tv * 2.f / (3.f * (H - 1) * W) / b_glob, cw = lambda_tv * 2.f / (3.f * H * (W - 1)) / b_glob;
     hipLaunchKernelGGL(k_pixel_losses, pgrid(P, b * 3), dim3(256), 0, st, S.cat, (const float*)nullptr, S.cidx, S.ms.gX[1], S.ms.h[1],
                        S.ms.w[1], H, W, 0.f, ch, cw, S.gimg, S.acc);
-    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
+    if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fxq_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
     launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), st);

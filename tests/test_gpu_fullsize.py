@@ -475,3 +475,111 @@ def test_config4_background_blend_full_size():
     err = (gen.frames.cpu() - (alpha * fr + (1 - alpha) * bg)).abs()
     assert err.max().item() < 2e-3 and err.mean().item() < 5e-5, (err.max().item(), err.mean().item())
     assert gen.init_noise.shape == (2, 4, 90, 120)
+
+
+def test_kernels_beyond_2g_elements_and_4gib_operands(L):
+    """Block-major passes larger than the default 1.5 M level-0 tokens carry activations with more than 2^31 elements / 4 GiB (3.46 M rows x 1280
+    channels at 120 frames of 1280x720 in ONE pass): every kernel family of the UNet pass is run once on such a tensor and checked on sampled rows
+    around the 2^31-element and 4-GiB marks and at the end against plain torch fp32 of those rows.  (The 8-phase GEMM addresses A relative to the
+    block's first row / image, so its 32-bit DMA offsets only span one tile.)"""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M = 3_460_000
+    rows = torch.tensor([0, 1, 255, 256, 1_677_721, 1_677_722, 1_677_800, 3_355_443, 3_355_444, 3_400_001, M - 257, M - 2, M - 1], device="cuda")
+    # ---- dense GEMM, K = 1280 (A = 8.9 GB): 8-phase 256x320 / LDS-DMA tile / automatic choice; residual + bias
+    A = torch.empty(M, 1280, device="cuda", dtype=H)
+    for i in range(0, M, 432_500):
+        A[i:i + 432_500] = torch.randn(min(432_500, M - i), 1280, device="cuda", generator=g).to(H)
+    W = (torch.randn(320, 1280, device="cuda", generator=g) / 1280 ** 0.5).to(H)
+    b = torch.randn(320, device="cuda", generator=g).to(H)
+    R = torch.randn(M, 320, device="cuda", generator=g).to(H)
+    ref = (A[rows].float() @ W.float().t() + b.float()).to(H).float() + R[rows].float()
+    outs = []
+    try:
+        for cfg in (14, 1, 0):
+            L.tcl_gemm_tune(cfg, 1 if cfg else 0)
+            C = torch.empty(M, 320, device="cuda", dtype=H)
+            L.tcl_gemm_f16(A, W, b, R, C, M, 320, 1280, 1280, 1280, 320, 320, 0, st())
+            assert rel(C[rows], ref) < 2e-3, cfg
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        del outs, C, R
+        # ---- GEGLU feed-forward shape: K = 320 -> N = 2560 (output 3.46 M x 1280 = 4.4e9 elements), strip kernel / 8-phase 256x256
+        X = A[:, :320].contiguous()
+        W2 = (torch.randn(2560, 320, device="cuda", generator=g) / 320 ** 0.5).to(H)
+        b2 = torch.randn(2560, device="cuda", generator=g).to(H)
+        f = X[rows].float() @ W2.float().t() + b2.float()
+        fr = f.to(H).float()
+        ref2 = torch.cat([fr[:, 64 * k:64 * k + 32] * F.gelu(fr[:, 64 * k + 32:64 * k + 64]) for k in range(40)], 1)
+        for cfg in (13, 12):
+            L.tcl_gemm_tune(cfg, 1)
+            C = torch.empty(M, 1280, device="cuda", dtype=H)
+            L.tcl_gemm_f16(X, W2, b2, 0, C, M, 2560, 320, 320, 320, 1280, 2560, 2, st())
+            assert rel(C[rows], ref2) < 2e-3, cfg
+        L.tcl_gemm_tune(0, 0)
+        # ---- LayerNorm, GroupNorm (two sources), concat, GEGLU-free elementwise on C (4.4e9 elements)
+        ga, be = torch.randn(1280, device="cuda", generator=g).to(H), torch.randn(1280, device="cuda", generator=g).to(H)
+        Y = torch.empty_like(C)
+        L.tcl_layernorm_f16(C, ga, be, Y, M, 1280, 1e-5, st())
+        assert rel(Y[rows], F.layer_norm(C[rows].float(), (1280,), ga.float(), be.float(), 1e-5)) < 2e-3
+        Bn, HW = 346, 10000                                                     # 346 samples x 10 000 pixels = M rows
+        ws = torch.zeros(int(L.tcl_groupnorm_workspace_bytes(Bn, 1280)), dtype=torch.uint8, device="cuda")
+        L.tcl_groupnorm_f16(C, 1280, 0, 0, ga, be, Y, Bn, HW, 32, 1e-5, 1, ws, st())
+        for smp in (0, 167, 168, 345):                                          # sample 168 starts at element 2.15e9
+            xs = C[smp * HW:(smp + 1) * HW].float()
+            want = F.silu(F.group_norm(xs.t()[None], 32, ga.float(), be.float(), 1e-5))[0].t()
+            assert rel(Y[smp * HW:(smp + 1) * HW], want) < 2e-3, smp
+        del Y
+        # ---- implicit 3x3 convolution: 240 images 90x160, 640 -> 320 channels (input 4.4 GB, 2.2e9 elements): 8-phase 256x320 vs the LDS-DMA tile
+        del C, X, A
+        Bc, Hh, Ww = 240, 90, 160
+        x = torch.empty(Bc, Hh, Ww, 640, device="cuda", dtype=H)
+        for i in range(0, Bc, 40):
+            x[i:i + 40] = torch.randn(40, Hh, Ww, 640, device="cuda", generator=g).to(H)
+        w = (torch.randn(320, 9 * 640, device="cuda", generator=g) / (9 * 640) ** 0.5).to(H)
+        ys = []
+        for cfg in (14, 1):
+            L.tcl_gemm_tune(cfg, 1)
+            y = torch.empty(Bc, Hh, Ww, 320, device="cuda", dtype=H)
+            L.tcl_conv3x3_f16(x, w, b, 0, y, Bc, Hh, Ww, 640, 320, 1, 1, 0, 0, 0, st())
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+        for smp in (0, 116, 117, 239):                                          # image 117 starts at element 1.08e9 x 2 B = beyond 2 GiB; 233+ beyond 4 GiB
+            want = F.conv2d(x[smp:smp + 1].permute(0, 3, 1, 2).float(), w.view(320, 3, 3, 640).permute(0, 3, 1, 2).float(), b.float(), padding=1).permute(0, 2, 3, 1)
+            assert rel(ys[0][smp:smp + 1], want) < 2e-3, smp
+    finally:
+        L.tcl_gemm_tune(0, 0)
+    torch.cuda.synchronize()
+
+
+def test_unet_pass_group_size_invariance_beyond_2g_elements():
+    """One xy step of 128 frames at 1280x720 latents (90 x 160) through `Generator._unet_xy` with the default 1.5 M-token passes (3 groups) and as ONE
+    block-major pass (3.7 M level-0 rows: the 1280-channel feed-forward tensors hold 4.7e9 elements, 9.4 GB).  Every kernel is batch-row
+    independent (GroupNorm partitions by HW, the K-split rule is 1 above 16 384 rows, attention runs per chunk, the bank chain visits the chunks
+    in the same order), so the noise prediction must be the SAME BITS -- which also checks every kernel of the pass beyond 2^31 elements."""
+    from types import SimpleNamespace
+    from tc_light_amd import sd15
+    from tc_light_amd.generate import Generator
+    from tc_light_amd.unet import UNetEngine
+    from tc_light_amd.vidtome import VidToMe
+    dev = torch.device("cuda")
+    sd = sd15.random_state_dict(sd15.unet_param_shapes(), seed=1)
+    n, h, w = 128, 90, 160
+    g = np.random.default_rng(3)
+    x = torch.from_numpy(g.standard_normal((n, 4, h, w)).astype(np.float32)).to(dev).half()
+    cc = torch.from_numpy(g.standard_normal((n, 4, h, w)).astype(np.float32)).to(dev).half()
+    text = torch.from_numpy(g.standard_normal((2, 154, 768)).astype(np.float32)).to(dev).half()
+    chunks = [list(range(i, min(i + 4, n))) for i in range(0, n, 4)]
+    outs = []
+    for cap in (1_500_000, 16_000_000):
+        unet = UNetEngine(sd, dev, VidToMe(dev, seed=7))
+        gen = Generator(unet, SimpleNamespace(), dict(max_tokens_per_pass=cap, seed=1))
+        gen.h, gen.w = h, w
+        noises = torch.zeros_like(x)
+        gen._unet_xy(x, cc, chunks, text, 801.0, noises)
+        torch.cuda.synchronize()
+        assert torch.isfinite(noises.float()).all()
+        outs.append(noises)
+        del unet, gen
+        torch.cuda.empty_cache()
+    d = (outs[0].float() - outs[1].float()).abs().max().item()
+    assert torch.equal(outs[0], outs[1]), f"one 3.7 M-row pass differs from three 1.5 M-token passes: max |d| = {d:.3e}"

@@ -36,7 +36,12 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
                                      #   from K ~ 1e7 up; kept for memory-bound cases).  "shard": the round-1 approximation, each rank's frame
                                      #   block as a video of its own (tracks cut at the block seams) -- NOT the reference's result.
     shard_post_opt=False,            # legacy spelling of post_opt_mode="shard"
-    max_tokens_per_pass=int(__import__("os").environ.get("TCL_MAX_TOKENS_PER_PASS", 1_500_000)))   # level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split
+    max_tokens_per_pass=int(__import__("os").environ.get("TCL_MAX_TOKENS_PER_PASS", 16_000_000)))
+    # ^ level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split into consecutive groups.  16 M = the
+    #   whole xy step of 555 frames at 1280x720 in ONE pass (8.6 M tokens, 90 GB peak at 300 frames): rounds 1-3 used 1.5 M (int32-sized tensors);
+    #   one group is 1.4 % faster (177.3 vs 179.8 s denoise, profiles/r4_ab_tokens_per_pass.txt) and, more important, its GEMM shapes do not
+    #   depend on the random chunk lengths (groups cut at a cap hold 153-156 frames depending on the draws: every step met un-tabled shapes and
+    #   the in-call tuner -- the 4.5 M line of that file).  tests/test_gpu_fullsize.py pins pass-size invariance (same bits) beyond 2^31 elements.
 
 
 class Generator:

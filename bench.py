@@ -496,7 +496,7 @@ def main():
         ms, fl, cnt = prof[0][:3] if prof else (0.0, 0.0, 0)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         is_base = (n_total, H, W, n_steps, a.epochs_exposure, a.epochs, a.no_multi_axis) == (300, 720, 1280, BASE_STEPS, 35, 70, False)
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = measured_traffic() if (H, W) == (720, 1280) else (None, None)      # (per-launch bytes of the 1280x720 launch mix)
         res = {
             "metric": "relit frames/sec end-to-end (denoise+2-stage opt)", "value": n_total * passes / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / (passes * n_steps) * 1e3, "higher_is_better": True,
@@ -559,7 +559,7 @@ def main():
             by2 = (56 + 48 + 24) * cfg["batch_size"] * H * W + 84 * int(K)
             t_it = info["timing"]["stage2"] / it2
             it1 = a.epochs_exposure * (-(-n_total // cfg["batch_size"]))
-            tr2, tr2_src = path2_traffic()
+            tr2, tr2_src = path2_traffic() if is_base else (None, None)      # the PMC passes were taken on the metric's clip: meaningless for any other workload
             res["roofline_path2"] = {"bound": "hbm", "kernel": "stage-2 iteration (unique-tensor optimisation: codebook gather, MS-SSIM / TV / flow losses + "
                                      "gradients, frame-ordered codebook gradient, Adam over all K rows)", "achieved": by2 / t_it / 1e9, "peak": 8000.0,
                                      "unit": "GB/s", "frac": by2 / t_it / 8e12, "traffic": tr2, "traffic_source": tr2_src,

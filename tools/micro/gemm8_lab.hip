@@ -84,6 +84,10 @@ int main(int argc, char** argv) {
         // stride 2 (UNet down-samplers; the VAE encoder's pad-0 variant with its asymmetric (0,1,0,1) padding): the tap masks of k_gemm8p
         {1, 0, 320, 0, 64, 90, 160, 320, 0, "conv 320->320 stride 2 @90x160 x64", 2, 1},
         {1, 0, 256, 0, 16, 180, 320, 256, 0, "conv 256->256 stride 2 pad 0 @180x320 x16 (VAE encoder)", 2, 0},
+        // K sweep at the level-0 Linear size: fixed cost per tile (prologue + epilogue) vs cost per K tile
+        {0, 368640, 320, 64, 0, 0, 0, 0, 0, "lin 368640x320x64"}, {0, 368640, 320, 128, 0, 0, 0, 0, 0, "lin 368640x320x128"},
+        {0, 368640, 320, 256, 0, 0, 0, 0, 0, "lin 368640x320x256"}, {0, 368640, 320, 640, 0, 0, 0, 0, 0, "lin 368640x320x640"},
+        {0, 95040, 960, 64, 0, 0, 0, 0, 0, "lin 95040x960x64"}, {0, 95040, 960, 640, 0, 0, 0, 0, 0, "lin 95040x960x640"},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const unsigned smask = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0x7u;      // bit s = time schedule s

@@ -345,10 +345,15 @@ __global__ __launch_bounds__(THR_BS) void k_thr_select(const unsigned long long*
     }
     __syncthreads();
     if (!s_last) return;
-    // thread t owns the 256 bins [65535 - 256 t - 255, 65535 - 256 t]: descending score order over t
+    // thread t owns the 256 bins [65535 - 256 t - 255, 65535 - 256 t]: descending score order over t.  Plain 16-B loads behind the acquire (the
+    // guide's last-arriver recipe; an agent-scope atomic load per bin made this scan a chain of 256 dependent round trips: 97 us per match in
+    // the first profiled pass of the round, more than the five launches it replaced)
     const int hi = 65535 - 256 * tid;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* bins = (const i32x4*)(hist16 + hi - 255);                   // ascending addresses: bins hi-255 .. hi
     int cnt = 0;
-    for (int q = 0; q < 256; ++q) cnt += __hip_atomic_load(hist16 + hi - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) { const i32x4 v = bins[q]; cnt += v[0] + v[1] + v[2] + v[3]; }
     sc[tid] = cnt;
     __syncthreads();
     for (int off = 1; off < THR_BS; off <<= 1) { const int v = tid >= off ? sc[tid - off] : 0; __syncthreads(); sc[tid] += v; __syncthreads(); }
@@ -359,14 +364,17 @@ __global__ __launch_bounds__(THR_BS) void k_thr_select(const unsigned long long*
     else if (tid == s_who) {
         int above = excl, thr = hi;
         for (int q = 0; q < 256; ++q) {
-            const int c = __hip_atomic_load(hist16 + hi - q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int c = hist16[hi - q];
             if (above + c >= r) { thr = hi - q; break; }
             above += c;
         }
         ctrl[2] = thr; ctrl[3] = r - above;                                   // threshold score; ties taken (lowest src index first)
     }
     __syncthreads();
-    for (int q = 0; q < 256; ++q) hist16[hi - q] = 0;                         // bins back to zero for the next match
+    i32x4* zb = (i32x4*)(hist16 + hi - 255);
+    const i32x4 z4 = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) zb[q] = z4;                                  // bins back to zero for the next match
     if (tid == 0) ctrl[0] = 0;
 }
 #define TOME_MAPS_BS 256

@@ -99,10 +99,12 @@ __device__ __forceinline__ float xhalf_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// (the body of k_flash for ONE block index: the kernel below calls it once, or -- the flag-gated exact pass behind the speculative kernel -- once per
+// flagged index of its stride class)
 template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC>
-__global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
-                                                  _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
-                                                  int kv_div, int nqb, int* __restrict__ flags) {
+__device__ __forceinline__ void flash_block(const int bid, const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                            _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
+                                            int kv_div, int nqb, int* __restrict__ flags) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = DPV * V_STRIDE * 2, SBYTES = KBYTES + VBYTES;
@@ -121,8 +123,7 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     constexpr int NT16 = 3;                                       // 16-row V^T tiles: rows 0-39 V, row 40 ones, 41-47 zero
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
 
-    const int bid = blockIdx.x, head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
-    if (!SPEC && flags && !flags[bid]) return;      // second pass behind the speculative kernel: only the blocks it flagged
+    const int head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, ql = lane & 31;
     const int q0 = qb_ * (128 * QB) + wid * (32 * QB);
     const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
@@ -546,6 +547,26 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
     }
 }
 
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC>
+__global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                                  _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
+                                                  int kv_div, int nqb, int* __restrict__ flags, int nblk) {
+    if constexpr (D == 40 && QB == 2 && !SPEC) {
+        // The exact kernel as the second pass behind the speculative one: normally NO block is flagged, and dispatching B H nqb (~3 000) blocks of
+        // 222 VGPRs / 66 KiB LDS just to read one word each took 57 us per attention call on the main stream (1.6 s per 300-frame pass).  The
+        // gated pass is launched with at most 512 blocks (one resident round); a block walks the flags of its stride class and runs the flagged ones.
+        if (flags) {
+            for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+                if (!flags[bid]) continue;
+                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+                __syncthreads();                  // the next item re-uses the LDS ring
+            }
+            return;
+        }
+    }
+    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Head_dim 40, software-pipelined across key tiles (k_flash40p).  The loop of k_flash is bound by VALU issue, and within one wave its
 // matrix and vector work are a dependency chain (QK^T -> max -> exp -> PV): the two pipes only overlap where the two waves of a SIMD
@@ -787,7 +808,9 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
         if (g_prof.ev.size() > 8192) flash_prof_drain(false);       // a 300-frame pass has ~1e5 launches: keep the live event count bounded
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>), dim3(B * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags);
+    const int nblk = B * H * nqb;
+    const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > 512) ? 512 : nblk;      // gated exact pass: one resident round of blocks walks the flags
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>), dim3(grid), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }

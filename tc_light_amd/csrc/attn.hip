@@ -28,10 +28,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define V_STRIDE 72   // halves: 144 B = 9 x 16 B (odd) -> the 16-lane groups of a ds_read_b128 are conflict-free
 
 // one_col >= 0: that column (a padding column, >= d) is set to 1 in valid rows (the K panel's ones column for the folded shift)
-__global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
-                            _Float16* __restrict__ dst, int Tp, int DP, long total_chunks, int one_col) {
+__device__ __forceinline__ void pack_rows_blk(int blk, int nblk, const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
+                                              _Float16* __restrict__ dst, int Tp, int DP, long total_chunks, int one_col) {
     const int cpr = DP / 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blk * blockDim.x + threadIdx.x; i < total_chunks; i += (long)nblk * blockDim.x) {
         int c8 = (int)(i % cpr) * 8; long row = i / cpr; int t = (int)(row % Tp); long bh = row / Tp; int h = (int)(bh % H); long b = bh / H;
         half8 v;
 #pragma unroll
@@ -46,6 +46,10 @@ __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int 
         *(half8*)(dst + i * 8) = v;
     }
 }
+__global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
+                            _Float16* __restrict__ dst, int Tp, int DP, long total_chunks, int one_col) {
+    pack_rows_blk(blockIdx.x, gridDim.x, src, bstride, ld, T, H, d, scale, dst, Tp, DP, total_chunks, one_col);
+}
 // Vt panel, tile-major: Vt[bh][tile][i][p(t)] = V[b][tile*64 + t][h*d + i], rows of V_STRIDE halves (64 keys + pad), so that one
 // 64-key tile is a contiguous LDS image (DPV x V_STRIDE).  Within every group of 16 keys the two middle blocks of 4 are swapped
 // (p swaps bits 2 and 3 of t): the S^T accumulator of the flash kernel leaves lane half hl with keys {4hl..4hl+3, 8+4hl..8+4hl+3}
@@ -55,10 +59,10 @@ __global__ void k_pack_rows(const _Float16* __restrict__ src, long bstride, int 
 // The 16x16x32 A fragment read has lane l fetch row l & 15 at key group l >> 4, and a ds_read_b128 lane group mixes rows 0-3 / 12-15 of one
 // key group with rows 4-11 of another: without the skew two pairs of lanes share a 16-B bank slot (SQ_LDS_BANK_CONFLICT = 1/3 of the kernel's
 // LDS cycles); with it all 16 slots of the 256-B bank window are distinct (exhaustive check of the four lane groups).
-__global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
-                                                 _Float16* __restrict__ vt, int ntiles, int DPV, int skew) {
+__device__ __forceinline__ void pack_vt_blk(int tile_idx, int bh, const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
+                                            _Float16* __restrict__ vt, int ntiles, int DPV, int skew) {
     extern __shared__ _Float16 tile[];   // [64][DPV+2]
-    const int t0 = blockIdx.x * 64, bh = blockIdx.y, h = bh % H; const long b = bh / H;
+    const int t0 = tile_idx * 64, h = bh % H; const long b = bh / H;
     const int st = DPV + 2, cpr = DPV / 8;
     for (int i = threadIdx.x; i < 64 * cpr; i += 256) {
         int r = i / cpr, c8 = (i % cpr) * 8, t = t0 + r;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
         for (int j = 0; j < 8; ++j) tile[r * st + c8 + j] = x[j];
     }
     __syncthreads();
-    _Float16* out = vt + ((long)bh * ntiles + blockIdx.x) * DPV * V_STRIDE;
+    _Float16* out = vt + ((long)bh * ntiles + tile_idx) * DPV * V_STRIDE;
     for (int i = threadIdx.x; i < DPV * 64; i += 256) {
         int dd = i / 64, r = i % 64;
         _Float16 val = tile[r * st + dd];
@@ -79,6 +83,20 @@ __global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v,
         if (skew && (((dd & 15) + 4) & 8)) pr ^= 16;
         out[dd * V_STRIDE + pr] = val;
     }
+}
+__global__ __launch_bounds__(256) void k_pack_vt(const _Float16* __restrict__ v, long bstride, int ld, int T, int H, int d,
+                                                 _Float16* __restrict__ vt, int ntiles, int DPV, int skew) {
+    pack_vt_blk(blockIdx.x, blockIdx.y, v, bstride, ld, T, H, d, vt, ntiles, DPV, skew);
+}
+// Q, K and V^T panels of one attention call in ONE launch (round 4: they were three -- 170 k launches of ~28 us per 300-frame pass on the main
+// stream): blocks [0, gq) pack Q rows, [gq, gq + gk) K rows, the rest one V^T tile each.  Same device functions, same bits.
+struct PackRows { const _Float16* src; long bstride; int ld, T, d; float scale; _Float16* dst; int Tp, DP; long total; int one_col; };
+__global__ __launch_bounds__(256) void k_pack_qkv(PackRows q, PackRows k, int gq, int gk, int H, const _Float16* __restrict__ v, long vbs, int ldv, int Tk, int d,
+                                                  _Float16* __restrict__ vt, int ntiles, int DPV, int skew) {
+    const int blk = blockIdx.x;
+    if (blk < gq) pack_rows_blk(blk, gq, q.src, q.bstride, q.ld, q.T, H, q.d, q.scale, q.dst, q.Tp, q.DP, q.total, q.one_col);
+    else if (blk < gq + gk) pack_rows_blk(blk - gq, gk, k.src, k.bstride, k.ld, k.T, H, k.d, k.scale, k.dst, k.Tp, k.DP, k.total, k.one_col);
+    else { const int i = blk - gq - gk; pack_vt_blk(i % ntiles, i / ntiles, v, vbs, ldv, Tk, H, d, vt, ntiles, DPV, skew); }
 }
 
 // Flash kernel.  Block = 4 waves; each wave owns QB blocks of 32 queries (QB = 2 for head_dim 40: the K and V^T fragments read
@@ -869,6 +887,14 @@ static int attention_pack(const void* q, int ldq, long qbs, const void* k, int l
     _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (((size_t)Bkv * H * Tkp * KS + 511) / 512) * 512;        // 1-KiB aligned
     long qc = (long)B * H * Tqp * (DP / 8), kc = (long)Bkv * H * Tkp * (KS / 8);
+    if (pack_q && pack_kv) {
+        const int gq = stream_grid(qc, 256, 2), gk = stream_grid(kc, 256, 2), nt = Tkp / 64;
+        PackRows pq = {(const _Float16*)q, qbs, ldq, Tq, d, scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1};
+        PackRows pk = {(const _Float16*)k, kbs, ldk, Tk, d, 1.f, Kp, Tkp, KS, kc, d == 40 ? d : -1};
+        hipLaunchKernelGGL(k_pack_qkv, dim3(gq + gk + nt * Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, pq, pk, gq, gk, H, (const _Float16*)v, vbs, ldv, Tk, d, Vt,
+                           nt, DPV, d == 40 ? 1 : 0);
+        return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+    }
     if (pack_q)
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(qc, 256, 2)), dim3(256), 0, st, (const _Float16*)q, qbs, ldq, Tq, H, d,
                            scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1);

@@ -14,6 +14,12 @@ configuration; VAE encode / decode and both optimiser stages are inside the time
 inputs: it warms the allocator pools and, when the committed GEMM tile table lacks a shape, the autotuner.  K that is a multiple of 20
 runs K/20 full passes.  Weights are seeded random tensors of the SD-1.5 / AutoencoderKL architecture, inputs synthetic (no network); all
 inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Behind the timed pass, untimed: a PROFILED pass of `--profile_steps` denoising steps on the same clip (HIP events around every head_dim-40 flash launch,
+every GEMM / conv call and every VidToMe match call -> `roofline`, `roofline_gemm`, `roofline_match`); the flash kernel alone on its largest launch
+shape (`roofline.alone`); at N = 1 the extras (`configs1`, `configs3`, `producers`, stage 2 at realistic track lengths) and the CPU baseline (the
+oracle on SURVEY 8(d)'s full sample, ~4 minutes of host time; `--cpu_bounded` for a ~30 s sample).  At N > 1 the line adds `per_rank` (phase seconds
+min / max over ranks, seconds and bytes per collective).
 """
 import argparse
 import ctypes

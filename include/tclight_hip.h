@@ -214,6 +214,8 @@ int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t
  * (one stream; may be re-used for any smaller na): every call leaves it all-zero again except two result words at a fixed offset (layout:
  * 4 KiB control | 65 536 score-histogram bins | keys).  Per call: the score kernel + two small launches (threshold select, maps). */
 size_t tcl_tome_match_workspace_bytes(int na);
+/* 1: C = 640 affine matches take the strip-resident kernel too (same maps; faster alone, slower beside the flash kernel: off by default; TCL_TOME640). */
+int tcl_tome_strip640(int enable);
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st);
 /* The same with a hint: the positions are affine -- a_pos[i] = i < a_split ? i : i + a_gap and b_pos[j] = b0 + j -- which is what every VidToMe

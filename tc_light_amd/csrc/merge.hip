@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 // (no index loads in the loop, so the counted vmcnt only ever sees the LDS-DMA).  XCD x sweeps dst split x % nsplit: its L2 holds one range.
 // LDS image of a stage: row R at R * 128, its 16-B chunk g stored at position g ^ ((R >> 1) & 7): the 16-lane groups of a ds_read_b128
 // (MI355X_MICROARCH.md, LDS table) then touch 16 distinct slots of the 256-B bank window.
-template <int NW>        // waves per block: 4 (128-src strip, two blocks per CU) or 8 (256-src strip, one block per CU: half the dst DMA per MFMA)
+template <int NW, int C = 320>        // waves per block: 4 (128-src strip, two blocks per CU) or 8 (256-src strip, one block per CU: half the dst DMA per MFMA); C = 640 (round 4): the level-1 matches, 160 VGPRs of strip
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
                                                           int b0, int nb, int tiles_dst, int nsplit, unsigned long long* __restrict__ keys) {
-    constexpr int C = 320, NST = C / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;       // src strip width, DMA pieces per wave and stage
+    constexpr int NST = C / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;       // src strip width, DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
     const int bid = blockIdx.x, x = bid & 7, per = 8 / nsplit;
@@ -259,14 +259,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
                 const char* db = smem + (step & 3) * STAGE;
                 // A fragments one k-slice ahead of the MFMAs that use them: the LDS latency of slice ks+1 hides under the 4 MFMAs of slice ks
                 // (with the reads issued right before their MFMAs the waves sat parked 45 % of their cycles, matrix pipe 44 % busy)
-                half8 fa[2][4];
+                constexpr bool PF = C <= 320;                                       // C = 640: the strip takes 160 VGPRs -- no second fragment set (the two waves of a SIMD cover for each other)
+                half8 fa[PF ? 2 : 1][4];
+                if (PF) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[0][a] = *(const half8*)(db + R * 128 + (((0 + hl) ^ ((R >> 1) & 7)) << 4)); }
+                    for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[0][a] = *(const half8*)(db + R * 128 + (((0 + hl) ^ ((R >> 1) & 7)) << 4)); }
+                }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < 3) {
+                    if (PF ? ks < 3 : true) {
+                        const int kn = PF ? ks + 1 : ks;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[(ks + 1) & 1][a] = *(const half8*)(db + R * 128 + (((2 * (ks + 1) + hl) ^ ((R >> 1) & 7)) << 4)); }
+                        for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[PF ? (kn & 1) : 0][a] = *(const half8*)(db + R * 128 + (((2 * kn + hl) ^ ((R >> 1) & 7)) << 4)); }
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
 #pragma unroll
                             for (int r = 0; r < 16; ++r) z[r] = 0.f;
                             acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][a], bfr[0], z, 0, 0, 0);
-                        } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks & 1][a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
+                        } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PF ? (ks & 1) : 0][a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
                     }
                 }
             }
@@ -472,6 +476,7 @@ size_t tcl_tome_match_workspace_bytes(int na) { return 4096 + 65536 * 4 + ((size
 // bipartite soft matching (merge.py:84-117 / :389-421 with align_batch): metric [Bt, T, C] normalised rows; src rows a_pos[na],
 // dst rows b_pos[nb] (positions in the T sequence, shared by the Bt batch entries); r src tokens get merged.
 // Outputs: mrg int32 [na - r + nb], unm int32 [T'] (indexed by input position; every a_pos/b_pos entry is written).
+static int g_tome640 = -1;
 static int tome_match_impl(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                            int* mrg, int* unm, void* ws, int affine, int a_split, int a_gap, int b0, hipStream_t st) {
     TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
@@ -492,21 +497,28 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
         (void)hipFuncSetAttribute((const void*)k_tome_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k_tome_match320<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
         (void)hipFuncSetAttribute((const void*)k_tome_match320<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
+        (void)hipFuncSetAttribute((const void*)(k_tome_match320<4, 640>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
         set = true;
     }
     static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
-    if (affine && C == 320 && nb >= 128 && use320) {
+    // C = 640 (level 1) on the strip kernel: built in round 4 (VERDICT r3 #3a), bit-identical, 5-24 % faster per call alone (tools/micro/bench_tome.py:
+    // 7 920 x 7 920: 269 -> 205 us) -- and 0.3 % SLOWER in the pass (same-box A/B, profiles/r4_ab_tome640.txt): its strip takes 160 of a wave's 256
+    // registers, so a block only starts on a SIMD with 256 free registers, i.e. not beside two flash waves.  Off by default; TCL_TOME640=1 selects it.
+    if (g_tome640 < 0) g_tome640 = getenv("TCL_TOME640") ? atoi(getenv("TCL_TOME640")) : 0;
+    const int use640 = g_tome640;
+    if (affine && (C == 320 || (C == 640 && use640)) && nb >= 128 && use320) {
         // 4-wave blocks by default.  The 8-wave form (256-src strips, one block per CU, half the dst DMA per MFMA) is 3-6 % faster with the GPU
         // to itself from ~13k x 13k tokens up, but in the pipeline the matching chain runs on a side stream beside the flash kernel: a 512-thread
         // block (352 VGPRs per SIMD lane, 64 KiB LDS) only starts on a CU that holds NO flash block, where a 4-wave block shares one with a flash
         // block -- in the profiled pass the 8-wave launches took 2.2 ms on average against 0.9 alone.  use320 = 8 selects it (tools/micro/bench_tome.py).
-        const int nw = use320 == 8 ? 8 : 4;
+        const int nw = (use320 == 8 && C == 320) ? 8 : 4;
         const int tsw = cdiv(na, 32 * nw), slots = nw == 8 ? 256 : 512;
         int nsplit = 1;
         while (nsplit < 8 && (long)tsw * nsplit < slots * 3 / 2) nsplit *= 2;
         while (nsplit > 1 && cdiv(td, nsplit) < 2) nsplit /= 2;
         const int per = 8 / nsplit, groups = cdiv(tsw, per);
-        if (nw == 8) hipLaunchKernelGGL(k_tome_match320<8>, dim3(groups * 8), dim3(512), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
+        if (C == 640) hipLaunchKernelGGL((k_tome_match320<4, 640>), dim3(groups * 8), dim3(256), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
+        else if (nw == 8) hipLaunchKernelGGL(k_tome_match320<8>, dim3(groups * 8), dim3(512), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
         else hipLaunchKernelGGL(k_tome_match320<4>, dim3(groups * 8), dim3(256), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
     } else {
     // each block keeps one dst tile and streams a run of src tiles; runs as long as possible while ~4 blocks per slot (256 CUs x 3) remain
@@ -523,6 +535,7 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     hipLaunchKernelGGL(k_tome_maps2, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, ctrl, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();
 }
+int tcl_tome_strip640(int enable) { g_tome640 = enable ? 1 : 0; return TCL_OK; }
 int tcl_tome_match_f16(const void* metric, long bstride, int Bt, int C, const int* a_pos, int na, const int* b_pos, int nb, int r,
                        int* mrg, int* unm, void* ws, hipStream_t st) {
     return tome_match_impl(metric, bstride, Bt, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, 0, 0, 0, 0, st);

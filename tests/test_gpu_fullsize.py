@@ -309,17 +309,20 @@ def test_unet_pass_full_size_deterministic(Hh, Ww, Fs, Lt):
     assert torch.equal(outs[0], outs[2])                 # the side-stream schedule changes timing only
 
 
-@pytest.mark.parametrize("N,F,randf,T2,src_len,ratio", [(14400, 4, 2, 0, 0, 0.6),        # config 3 local merge, dst frame in the middle (two src runs)
-                                                         (14400, 4, 0, 0, 0, 0.6),        # dst = first frame
-                                                         (5760, 3, 2, 0, 0, 0.9),         # yt plane of a 64-frame window, dst = last frame, ragged tiles
-                                                         (0, 0, 0, 63360, 31680, 0.5),    # config 3 two-set (global) merge, local tokens are src
-                                                         (0, 0, 0, 40777, 17017, 0.8),    # ragged sizes, config 4's global ratio
-                                                         (300, 4, 1, 0, 0, 0.6),          # smaller than one dst split; last dst tile moved back
-                                                         (100, 4, 1, 0, 0, 0.6)])         # fewer than 128 dst tokens: the strip kernel hands over to the tile kernel
-def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len, ratio):
-    """k_tome_match320 (src strip in registers, running maximum over the dst sweep; taken through tcl_tome_match_affine_f16 for C = 320)
-    must produce the SAME maps as the general tile-epilogue kernel (tcl_tome_match_f16), bit for bit: same MFMA, same K order, same key."""
-    C = 320
+@pytest.mark.parametrize("N,F,randf,T2,src_len,ratio,C", [(14400, 4, 2, 0, 0, 0.6, 320),        # config 3 local merge, dst frame in the middle (two src runs)
+                                                         (3600, 4, 2, 0, 0, 0.6, 640),    # the same at level 1 (C = 640: the 160-VGPR strip, round 4)
+                                                         (0, 0, 0, 15840, 7920, 0.5, 640),     # level-1 two-set (global) merge
+                                                         (1440, 3, 0, 0, 0, 0.9, 640),    # level-1 yt plane, ragged tiles
+                                                         (14400, 4, 0, 0, 0, 0.6, 320),        # dst = first frame
+                                                         (5760, 3, 2, 0, 0, 0.9, 320),         # yt plane of a 64-frame window, dst = last frame, ragged tiles
+                                                         (0, 0, 0, 63360, 31680, 0.5, 320),    # config 3 two-set (global) merge, local tokens are src
+                                                         (0, 0, 0, 40777, 17017, 0.8, 320),    # ragged sizes, config 4's global ratio
+                                                         (300, 4, 1, 0, 0, 0.6, 320),          # smaller than one dst split; last dst tile moved back
+                                                         (100, 4, 1, 0, 0, 0.6, 320)])         # fewer than 128 dst tokens: the strip kernel hands over to the tile kernel
+def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len, ratio, C):
+    """k_tome_match320 (src strip in registers, running maximum over the dst sweep; taken through tcl_tome_match_affine_f16 for C = 320 and,
+    since round 4, C = 640) must produce the SAME maps as the general tile-epilogue kernel (tcl_tome_match_f16), bit for bit: same MFMA, same K
+    order, same key.  The workspace must come back all-zero except the two result words of the control block."""
     g = torch.Generator(device="cuda").manual_seed(N + T2 + randf)
     if N:
         T = F * N
@@ -340,6 +343,7 @@ def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len,
     L.tcl_tome_normalize_f16(x, metric, 2 * T, C, st())
     r = min(na, int(na * ratio))
     outs = []
+    L.tcl_tome_strip640(1 if C == 640 else 0)             # (the C = 640 strip kernel is opt-in: slower beside the flash kernel)
     for affine in (False, True):
         ws = torch.zeros(L.tcl_tome_match_workspace_bytes(na), dtype=torch.uint8, device="cuda")
         mrg = torch.full((na - r + nb,), -1, dtype=I32, device="cuda")
@@ -349,8 +353,9 @@ def test_tome_match_strip_kernel_equals_tile_kernel(L, N, F, randf, T2, src_len,
         else:
             L.tcl_tome_match_f16(metric, T * C, 2, C, a_pos, na, b_pos, nb, r, mrg, unm, ws, st())
         torch.cuda.synchronize()
-        assert not ws[:2048].any() and not ws[4096: 4096 + na * 8].any()
+        assert not ws[:3072].any() and not ws[3072 + 16:].any()       # (ints 768..771 of the control block: tickets (zero again), thr, take)
         outs.append((mrg, unm))
+    L.tcl_tome_strip640(0)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 

@@ -4,7 +4,7 @@ import torch
 from tc_light_amd.lib import lib
 L=lib(); H=torch.float16; I=torch.int32
 def st(): return torch.cuda.current_stream().cuda_stream
-for na,nb,C in [(43200,14400,320),(31680,31680,320),(32400,10800,320),(23760,23760,320),(17280,5760,320),(12672,12672,320),(8100,2700,640)]:
+for na,nb,C in [(43200,14400,320),(31680,31680,320),(32400,10800,320),(23760,23760,320),(17280,5760,320),(12672,12672,320),(8100,2700,640),(10800,3600,640),(7920,7920,640),(5940,5940,640)]:
     T=na+nb
     x=torch.randn(2,T,C,device='cuda').to(H); m=torch.empty_like(x)
     L.tcl_tome_normalize_f16(x,m,2*T,C,st())

@@ -481,9 +481,6 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
                            int* mrg, int* unm, void* ws, int affine, int a_split, int a_gap, int b0, hipStream_t st) {
     TCL_CHECK_ARG(metric && a_pos && b_pos && mrg && unm && ws && Bt > 0 && na > 0 && nb > 0 && r >= 0 && r <= na && na <= 64 * 1024 && C % 64 == 0);
     TclProfScope ps(TCL_PROF_MATCH, st, 2.0 * na * nb * C * Bt);
-    // ws: [histograms 512 ints + 2 selector words | keys na x 8 B | aux]; histograms and keys are all-zero on entry (the caller zeroes the
-    // workspace once) and are left all-zero -- the histograms sit at a FIXED offset so that a workspace re-used for a different na never
-    // maps them onto a previous call's (non-zero) aux words
     // ws: [4 KiB control: ints 768.. = tickets, thr, take | 65 536 histogram bins | keys na x 8 B]; bins, tickets and keys are all-zero on entry
     // (the caller zeroes the workspace once) and are left all-zero; every region sits at a fixed offset or behind everything else, so a
     // workspace re-used for another na never shows a match a previous match's scratch

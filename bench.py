@@ -402,6 +402,8 @@ def main():
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):
         ge.build()
+    if world > 1:
+        dist.barrier()                                 # the other ranks load the library rank 0 may just have built
     from tc_light_amd import sd15
     from tc_light_amd.generate import Generator
     from tc_light_amd.lib import lib

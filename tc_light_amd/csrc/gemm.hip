@@ -20,6 +20,7 @@
 #include <string.h>
 #include "../../include/tclight_hip.h"
 #include <stdlib.h>
+#include <math.h>
 #include <unordered_map>
 #include "gemm_conv.h"
 #include "prof.h"
@@ -574,6 +575,7 @@ struct TuneKeyHash {
     }
 };
 static std::unordered_map<TuneKey, int, TuneKeyHash> g_tune_cache;
+static std::unordered_map<TuneKey, int, TuneKeyHash> g_near_cache;      // un-tabled shapes -> the tile of their nearest-M twin (0 = none)
 #define TUNE_MAGIC "!tcl-gemm-table gfx950 v4"        // bump when tiles / schedules change: older tables are refused, not trusted
 static int g_autotune = 1;
 
@@ -616,6 +618,31 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
         const int c = (cfg_ok(it->second, M, N, K, ldc, ldr, hasr, act, cp) && tile_ok(it->second, M, N, K, splits)) ? it->second : fallback;
         return run_cfg(c, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     }
+    // A shape the table does not hold, but whose twin with another row count it does (the same layer in a pass over another number of frames: a
+    // group cut at a chunk boundary, the last window of a clip), takes the twin's tile when the row counts are within 2.5x of each other: the best
+    // tile moves little with M at these sizes, timing costs a host sync and ~40 launches, and every tile yields the same bits.  The guess lives in
+    // its own cache (tcl_gemm_tune_save writes measured entries only).  TCL_GEMM_NEAR=0: off (the re-tuning tools measure every shape).
+    static const bool near_on = !(getenv("TCL_GEMM_NEAR") && atoi(getenv("TCL_GEMM_NEAR")) == 0);
+    if (near_on) {
+        auto nt = g_near_cache.find(key);
+        int c = nt != g_near_cache.end() ? nt->second : -1;
+        if (c < 0) {
+            double bd = 1e30;
+            c = 0;
+            for (const auto& kv : g_tune_cache) {
+                TuneKey k = kv.first;
+                const int m = k.M;
+                k.M = M;
+                if (!(k == key)) continue;
+                const double dd = fabs(log((double)m / (double)M));
+                if (dd < bd) { bd = dd; c = kv.second; }
+            }
+            if (bd > log(2.5)) c = 0;
+            g_near_cache[key] = c;
+        }
+        if (c > 0 && cfg_ok(c, M, N, K, ldc, ldr, hasr, act, cp) && tile_ok(c, M, N, K, splits))
+            return run_cfg(c, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
+    }
     if (g_autotune == 2)      // table-only mode: shapes the loaded table does not know take the static heuristic (no timing, no host sync)
         return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs (tile_ok)
@@ -654,7 +681,7 @@ extern "C" {
 
 int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = ws ? bytes : 0; return TCL_OK; }
 int tcl_gemm_tune(int cfg, int splits) { g_tune_cfg = cfg; g_tune_splits = splits; return TCL_OK; }
-int tcl_gemm_autotune(int enable) { g_autotune = enable; if (!enable) g_tune_cache.clear(); return TCL_OK; }
+int tcl_gemm_autotune(int enable) { g_autotune = enable; g_near_cache.clear(); if (!enable) g_tune_cache.clear(); return TCL_OK; }
 
 // Persistent tuning table: one text line per problem shape, "conv M N K act hasr Hin Win Cin stride Hup cfg".
 int tcl_gemm_tune_save(const char* path) {
@@ -686,6 +713,7 @@ int tcl_gemm_tune_load(const char* path) {
         g_tune_cache[k] = cfg;
     }
     fclose(f);
+    g_near_cache.clear();
     return TCL_OK;
 }
 size_t tcl_gemm_tune_size(void) { return g_tune_cache.size(); }

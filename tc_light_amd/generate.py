@@ -7,6 +7,7 @@ Python sequences kernel launches and collectives; tensors never leave the device
 per-iteration host sync (the reference syncs on loss.item() and moves the token bank through the CPU).
 """
 import math
+import os
 import time
 from types import SimpleNamespace
 
@@ -36,7 +37,7 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
                                      #   from K ~ 1e7 up; kept for memory-bound cases).  "shard": the round-1 approximation, each rank's frame
                                      #   block as a video of its own (tracks cut at the block seams) -- NOT the reference's result.
     shard_post_opt=False,            # legacy spelling of post_opt_mode="shard"
-    max_tokens_per_pass=int(__import__("os").environ.get("TCL_MAX_TOKENS_PER_PASS", 16_000_000)))
+    max_tokens_per_pass=int(os.environ.get("TCL_MAX_TOKENS_PER_PASS", 16_000_000)))
     # ^ level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split into consecutive groups.  16 M = the
     #   whole xy step of 555 frames at 1280x720 in ONE pass (8.6 M tokens, 90 GB peak at 300 frames): rounds 1-3 used 1.5 M (int32-sized tensors);
     #   one group is 1.4 % faster (177.3 vs 179.8 s denoise, profiles/r4_ab_tokens_per_pass.txt) and, more important, its GEMM shapes do not
@@ -101,32 +102,68 @@ class Generator:
             groups.append(cur)
         return groups
 
+    def _run_groups(self, groups, Hh, Ww, t, text, pack, unpack):
+        """The UNet passes of one list of chunk groups.  pack(grp) -> (xin, idx, n); unpack(eps, idx, n).  TCL_SKEW=1: the groups go through
+        two at a time, half a transformer block apart (unet.py forward_pair) -- a lone group of several chunks is cut in two first; same bits."""
+        mode = os.environ.get("TCL_SKEW", "0")                  # "cut": the same groups, one after the other (the A/B and parity partner of "1")
+        if mode != "0":
+            cut = []
+            for grp in groups:
+                if len(grp) < 2:
+                    cut.append(grp)
+                    continue
+                tot = sum(len(c) for c in grp)
+                heads = [sum(len(c) for c in grp[:k]) for k in range(1, len(grp))]
+                k = 1 + min(range(len(heads)), key=lambda i: abs(2 * heads[i] - tot))         # the chunk boundary nearest to half the frames
+                cut += [grp[:k], grp[k:]]
+            groups = cut
+            while mode != "cut" and len(groups) >= 2:
+                ga, gb = groups[0], groups[1]
+                groups = groups[2:]
+                (xa, ia, na), (xb, ib, nb) = pack(ga), pack(gb)
+                ea, eb = self.unet.forward_pair(xa, [len(c) for c in ga], xb, [len(c) for c in gb], Hh, Ww, t, text, cfg_pair=True)
+                unpack(ea, ia, na); unpack(eb, ib, nb)
+        for grp in groups:
+            xin, idx, n = pack(grp)
+            eps = self.unet.forward_many(xin, [len(c) for c in grp], Hh, Ww, t, text, cfg_pair=True)     # the pack kernel wrote both halves
+            unpack(eps, idx, n)
+
     def _unet_xy(self, x, cc, chunks, text, t, noises):
         """pred_noise on the xy chunks of one step (generate.py:220-224, 288-352): chunks = lists of local frame ids, reference order.
         The chunks go through the UNet in block-major passes (`forward_many`, see unet.py): one pack, one unpack per pass."""
         L = self.L
-        for grp in self._groups(chunks, self.h * self.w):
+
+        def pack(grp):
             frames = [f for c in grp for f in c]
             n = len(frames)
             idx = torch.tensor(frames, dtype=I32, device=self.dev)
             xin = torch.empty(2 * n, self.h, self.w, 8, dtype=H16, device=self.dev)
             L.tcl_pack_latents_f16(x, cc, idx, n, 0, 0, 0, self.h, self.w, xin, stream())
-            eps = self.unet.forward_many(xin, [len(c) for c in grp], self.h, self.w, t, text, cfg_pair=True)     # the pack kernel wrote both halves
+            return xin, idx, n
+
+        def unpack(eps, idx, n):
             L.tcl_unpack_cfg_f16(eps, idx, n, 0, 0, 0, self.h, self.w, float(self.cfg.guidance_scale), 0, 1.0, 0, noises, stream())
+
+        self._run_groups(self._groups(chunks, self.h * self.w), self.h, self.w, t, text, pack, unpack)
 
     def _unet_yt(self, x_full, cc_full, items, nt_full, text_t, t):
         """pred_noise on the yt chunks of one frame window: 'n c h w -> w c n h' (generate.py:265-273); items share (start, length)."""
         L = self.L
         sl, nwin, _, scale_upto, nkeep = items[0]
-        for grp in self._groups([it[2] for it in items], nwin * self.h):
+
+        def pack(grp):
             cols = [c for ch in grp for c in ch]
             n = len(cols)
             idx = torch.tensor(cols, dtype=I32, device=self.dev)
             xin = torch.empty(2 * n, nwin, self.h, 8, dtype=H16, device=self.dev)
             L.tcl_pack_latents_f16(x_full, cc_full, idx, n, 1, sl, nwin, self.h, self.w, xin, stream())
-            eps = self.unet.forward_many(xin, [len(ch) for ch in grp], nwin, self.h, t, text_t, cfg_pair=True)
+            return xin, idx, n
+
+        def unpack(eps, idx, n):
             L.tcl_unpack_cfg_f16(eps, idx, n, 1, sl, nwin, self.h, self.w, float(self.cfg.guidance_scale), scale_upto, math.sqrt(0.5),
                                  nkeep, nt_full, stream())
+
+        self._run_groups(self._groups([it[2] for it in items], nwin * self.h), nwin, self.h, t, text_t, pack, unpack)
 
     def _yt_items(self, w_chunks):
         """(window start, length, columns, scale_upto, nkeep) in the reference's loop order (generate.py:265-278)."""

@@ -285,8 +285,10 @@ class UNetEngine:
                 self._side = torch.cuda.Stream(device=self.dev, priority=-1 if prio == "high" else 0)
         return self._side
 
-    def _transformer(self, p, x, B, Fs, Hh, Ww, text, pair_half=False):
-        """x [B*N, C] with B = 2*sum(Fs) samples: the unconditional samples of all chunks (chunk order), then the conditional ones.
+    def _transformer(self, p, x, B, Fs, Hh, Ww, text, pair_half=False, skew=False, chunks=None):
+        """(A generator: use with `yield from`.  skew=False never yields.  skew=True yields "M" before the block's matching chain
+        is issued, "A" before its attn1 launches and "F" behind them -- the points at which forward_pair switches between its two groups.)
+        x [B*N, C] with B = 2*sum(Fs) samples: the unconditional samples of all chunks (chunk order), then the conditional ones.
         Everything is batched over the chunks except attn1 of the merging levels, which runs chunk by chunk in the reference order
         because each chunk's merge uses -- and updates -- this block's global-token bank (patch.py:59-82).
         pair_half: x holds only the FIRST half of the B samples (see forward_many: the two classifier-free-guidance halves are identical up to
@@ -314,41 +316,63 @@ class UNetEngine:
             # The matching chain (bank order, dozens of small launches per chunk) runs on a side stream, ahead of the attention of the
             # chunks already matched: only merge(c) -> merge(c+1) and merge(c) -> attention(c) are real dependencies, so the small
             # kernels of chunk c+1 fill the tails of chunk c's QKV GEMM / flash launches instead of serialising with them.
-            main = torch.cuda.current_stream()
-            # (Always on the side stream, single-chunk passes included: the banks then live in that stream's allocator pool for good.)
-            two = os.environ.get("TCL_TOME_STREAM", "1") != "0"
-            side = self._side_stream() if two else main
-            if two:
-                side.wait_stream(main)                          # n1 is ready
-            # TCL_QKV_SIDE=1: the chunk's QKV projection and panel packing ride on the side stream too (they only depend on the merge, and the main
-            # stream is the critical path of the pass).  Measured: -0.7 % denoise time on a same-box A/B, +0.4 % frames/s on the full clip, but the
-            # flash kernel's in-pass rate drops 3.5 % (more work shares the matrix pipes with it): off by default.
-            qkv_side = two and os.environ.get("TCL_QKV_SIDE", "0") != "0"
-            for ci, F in enumerate(Fs):
-                self.tome.select_chunk(ci)
-                with torch.cuda.stream(side):
-                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
-                                                             metric=m1[off * N:] if m1 is not None else None, ne=ne)     # merged [ne, T, C]
-                    packed = None
-                    if qkv_side:
-                        qkv = o.gemm(merged, blk["qkv"], M=ne * T)
-                        packed = o.attention_pack(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d)
-                if two:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    main.wait_event(ev)
-                    for tns in ((qkv,) + packed) if qkv_side else (merged,):       # allocated on the side stream's pool, read on the main stream
-                        tns.record_stream(main)
-                    if unm is not None:
-                        unm.record_stream(main)
-                if not qkv_side:
+            def attend(F, off, merged, unm, T, qkv, packed):
+                if qkv is None:
                     qkv = o.gemm(merged, blk["qkv"], M=ne * T)
                 a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half,
                                 packed=packed)
                 y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=ne * T)
                 self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C, ne)  # u_a(...) + x (patch.py:178-179)
                 self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C, 2.0 * ne * T * C * C * 4 + 4.0 * ne * T * T * C)
+
+            if skew:
+                yield "M"
+            main = torch.cuda.current_stream()
+            # (Always on the side stream, single-chunk passes included: the banks then live in that stream's allocator pool for good.)
+            two = os.environ.get("TCL_TOME_STREAM", "1") != "0"
+            side = self._side_stream() if two else main
+            if two:
+                side.wait_stream(main)                          # n1 is ready (skew: and the other group's attn1, issued just before, is done)
+            # TCL_QKV_SIDE=1: the chunk's QKV projection and panel packing ride on the side stream too (they only depend on the merge, and the main
+            # stream is the critical path of the pass).  Measured: -0.7 % denoise time on a same-box A/B, +0.4 % frames/s on the full clip, but the
+            # flash kernel's in-pass rate drops 3.5 % (more work shares the matrix pipes with it): off by default.
+            qkv_side = two and os.environ.get("TCL_QKV_SIDE", "0") != "0"
+            pend = []
+
+            def hand_over(merged, unm, qkv, packed, ev):
+                if two:
+                    main.wait_event(ev)
+                    for tns in ((qkv,) + packed) if qkv_side else (merged,):       # allocated on the side stream's pool, read on the main stream
+                        tns.record_stream(main)
+                    if unm is not None:
+                        unm.record_stream(main)
+
+            for ci, F in enumerate(Fs):
+                self.tome.select_chunk(ci, chunks)
+                with torch.cuda.stream(side):
+                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
+                                                             metric=m1[off * N:] if m1 is not None else None, ne=ne)     # merged [ne, T, C]
+                    qkv = packed = None
+                    if qkv_side:
+                        qkv = o.gemm(merged, blk["qkv"], M=ne * T)
+                        packed = o.attention_pack(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d)
+                ev = None
+                if two:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                if skew:                                        # the whole chain of the group first; its attn1 when forward_pair comes back
+                    pend.append((F, off, merged, unm, T, qkv, packed, ev))
+                else:
+                    hand_over(merged, unm, qkv, packed, ev)
+                    attend(F, off, merged, unm, T, qkv, packed)
                 off += F
+            if skew:
+                yield "A"
+                for F, off_c, merged, unm, T, qkv, packed, ev in pend:
+                    hand_over(merged, unm, qkv, packed, ev)
+                    attend(F, off_c, merged, unm, T, qkv, packed)
+                del pend
+                yield "F"
             # (running the attention of alternate chunks on a second stream as well was measured: no further gain)
         if pair_half:                                           # from here on the halves differ (text): both exist
             h, x = torch.cat([h, h]), torch.cat([x, x])
@@ -382,6 +406,43 @@ class UNetEngine:
     # norms, cross-attention, feed-forward and the non-merging levels see 8-31x more rows per GEMM and one launch instead of one
     # per chunk, and every weight matrix is streamed once per step.
     def forward_many(self, x_in, Fs, Hh, Ww, t, text, cfg_pair=False):
+        """One block-major pass; see _forward_gen for the arguments."""
+        g = self._forward_gen(x_in, Fs, Hh, Ww, t, text, cfg_pair)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    # Two groups of chunks through the UNet half a transformer block apart (TCL_SKEW=1, generate.py).  `tools/micro/corun.py` (round 4,
+    # profiles/r4_corun.txt): the matching chain beside the head_dim-40 flash kernel gains NOTHING over running the two one after the other
+    # (1.00x), beside a store-bound Linear or a 3x3 conv it gains 6-11 %.  In one block-major pass the chain of a block can only run beside that
+    # block's own attn1 -- nothing else of the pass is ready.  With two groups A (the first chunks) and B there is: A's chain of block b is issued
+    # behind B's attn1 of block b-1 and runs beside B's cross-attention / feed-forward / ResNet blocks; B's chain of block b behind A's attn1
+    # of block b, beside A's.  Order on the main stream per merging block:  F(B,b-1) P(B,b) | A(A,b) | F(A,b) P(A,b+1) | A(B,b)  (P = everything
+    # up to norm1, A = attn1, F = the rest), on the side stream  M(A,b) | M(B,b): bank order is A's chunks, then B's, in every block, as in the
+    # reference loop -- and every kernel is batch-row independent, so the result is the one of a single pass, bit for bit.
+    def forward_pair(self, xa, Fsa, xb, Fsb, Hh, Ww, t, text, cfg_pair=False):
+        ca = list(self.tome.begin_step(Fsa, (Hh, Ww)))          # the draws in the reference's chunk order: A's chunks, then B's
+        cb = list(self.tome.begin_step(Fsb, (Hh, Ww)))
+        gens = {"a": self._forward_gen(xa, Fsa, Hh, Ww, t, text, cfg_pair, skew=True, chunks=ca),
+                "b": self._forward_gen(xb, Fsb, Hh, Ww, t, text, cfg_pair, skew=True, chunks=cb)}
+        res = {}
+
+        def step(k):
+            if k in res:
+                return
+            try:
+                next(gens[k])
+            except StopIteration as e:
+                res[k] = e.value
+
+        step("a"); step("a")                                    # A runs two segments ahead: [P0] [M0]
+        while len(res) < 2:
+            step("b"); step("a")
+        return res["a"], res["b"]
+
+    def _forward_gen(self, x_in, Fs, Hh, Ww, t, text, cfg_pair=False, skew=False, chunks=None):
         """x_in [2*Ftot, Hh, Ww, 8] f16 (latents | concat_conds; Ftot = sum(Fs) samples in chunk order, twice: uncond, cond);
         text [2, L, 768] f16 (uncond, cond).  Fs: chunk lengths in the reference's chunk order.  -> eps [2*Ftot, Hh, Ww, 4] f16.
         cfg_pair: the caller GUARANTEES x_in[Ftot:] == x_in[:Ftot] (the classifier-free-guidance pair of generate.py:342-347: `torch.cat([latents] * 2)`
@@ -395,7 +456,8 @@ class UNetEngine:
         half = bool(cfg_pair) and os.environ.get("TCL_CFG_DEDUP", "1") != "0"
         Bh = Ftot if half else B                                # samples through the text-free prefix
         tproj = self._temb(t)
-        self.tome.begin_step(Fs, (Hh, Ww))                      # every chunk's lock-step draws, in chunk order (patch.py:206-231)
+        if chunks is None:
+            self.tome.begin_step(Fs, (Hh, Ww))                  # every chunk's lock-step draws, in chunk order (patch.py:206-231)
         col = o.empty(Bh * Hh * Ww, 128)
         L.tcl_im2col3x3_small_f16(x_in, col, Bh, Hh, Ww, w["conv_in"][2], 128, stream())
         h = o.gemm(col, w["conv_in"][0], w["conv_in"][1])
@@ -410,7 +472,7 @@ class UNetEngine:
                 h = self._resblock(f"down_blocks.{i}.resnets.{j}.", h, Bh if first else B, hh, ww, tproj, rep=2 if first else 1)
                 c = co
                 if i < 3:
-                    h = self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text, pair_half=first)
+                    h = yield from self._transformer(f"down_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text, pair_half=first, skew=skew, chunks=chunks)
                 skips.append((h, c))
             if i < 3:
                 h, hh2, ww2 = o.conv3x3(h, B, hh, ww, c, *w[f"down{i}"], stride=2, pad=1)
@@ -419,7 +481,7 @@ class UNetEngine:
                 sizes.append((hh, ww))
                 skips.append((h, c))
         h = self._resblock("mid_block.resnets.0.", h, B, hh, ww, tproj)
-        h = self._transformer("mid_block.attentions.0.", h, B, Fs, hh, ww, text)
+        h = yield from self._transformer("mid_block.attentions.0.", h, B, Fs, hh, ww, text, skew=skew, chunks=chunks)
         h = self._resblock("mid_block.resnets.1.", h, B, hh, ww, tproj)
         level = 3
         for i, co in enumerate(sd15.BLOCK_OUT[::-1]):
@@ -428,7 +490,7 @@ class UNetEngine:
                 h = self._resblock(f"up_blocks.{i}.resnets.{j}.", h, B, hh, ww, tproj, skip=sk, cskip=cs)
                 del sk
                 if i > 0:
-                    h = self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text)
+                    h = yield from self._transformer(f"up_blocks.{i}.attentions.{j}.", h, B, Fs, hh, ww, text, skew=skew, chunks=chunks)
             if i < 3:
                 level -= 1
                 h, hh2, ww2 = o.conv3x3(h, B, hh, ww, co, *w[f"up{i}"], up=sizes[level])   # nearest upsample fused in the gather

@@ -72,9 +72,11 @@ class VidToMe:
                 randfs = self.round_frames(F)[1]
                 coin = float(self.rng.random())
             self._chunks.append((F, randfs, coin))
+        return self._chunks
 
-    def select_chunk(self, i):
-        self.F, self.randfs, self.coin = self._chunks[i]
+    def select_chunk(self, i, chunks=None):
+        """chunks: a list begin_step returned earlier (two groups of chunks in flight: unet.py forward_pair); default the last begin_step's."""
+        self.F, self.randfs, self.coin = (chunks if chunks is not None else self._chunks)[i]
         self.randf = self.randfs[0] if self.randfs else -1
 
     def end_forward(self):

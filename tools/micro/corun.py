@@ -1,5 +1,6 @@
 """Do two of the pass's heavy kernels gain from running side by side?  Stream A loops the head_dim-40 flash call, stream B a Linear / conv GEMM or
-the VidToMe match; time for both loops alone and together (same iteration counts).  gain = (tA + tB) / t_together."""
+the VidToMe match; time for both loops alone and together (same iteration counts).  gain = (tA + tB) / t_together.
+CORUN_A=match puts the match call on stream A (is the match a better neighbour of the store-bound Linears than of the flash kernel?)."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tc_light_amd.lib import lib
@@ -39,7 +40,8 @@ def timed(jobs):
     for s in {j[1] for j in jobs}: torch.cuda.current_stream().wait_stream(s)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)
-fl = flash_fn()
+fl = match_fn() if os.environ.get("CORUN_A", "flash") == "match" else flash_fn()     # CORUN_A=match: the match on stream A instead of the flash call
+nameA = os.environ.get("CORUN_A", "flash")
 partners = [("linear 115200x2560x320 GEGLU", gemm_fn(115200, 2560, 320, 2)), ("linear 115200x320x1280", gemm_fn(115200, 320, 1280)),
             ("conv3x3 8x90x160 320->320", conv_fn(8, 90, 160, 320, 320)), ("conv3x3 8x23x40 1280->1280", conv_fn(8, 23, 40, 1280, 1280)),
             ("match 43200x14400", match_fn()), ("flash (second copy)", flash_fn())]
@@ -49,4 +51,4 @@ for name, fn in partners:
     nA, nB = 40, max(1, int(40 * tA1 / tB1))            # equal time on both sides when alone
     tA, tB = timed([(fl, sA, nA)]), timed([(fn, sB, nB)])
     tAB = timed([(fl, sA, nA), (fn, sB, nB)])
-    print(f"flash x{nA} {tA:7.1f} ms | {name} x{nB} {tB:7.1f} ms | together {tAB:7.1f} ms -> gain {(tA + tB) / tAB:5.3f}")
+    print(f"{nameA} x{nA} {tA:7.1f} ms | {name} x{nB} {tB:7.1f} ms | together {tAB:7.1f} ms -> gain {(tA + tB) / tAB:5.3f}")

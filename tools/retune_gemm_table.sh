@@ -3,6 +3,7 @@
 # BASELINE configs[1] (30 x 960 x 720) and configs[3] (60 x 960 x 720, VidToMe 0.9 / 0.8) is timed on first use over the valid tiles (csrc/gemm.hip tile_ok) and the winners are saved.
 # Usage (GPU box): tools/retune_gemm_table.sh   -> gpurun_out/gemm_tune_gfx950.txt (copy it over the committed table)
 set -e
+export TCL_GEMM_NEAR=0        # measure every shape: no tile borrowed from a nearest-M twin (csrc/gemm.hip)
 mkdir -p gpurun_out
 OUT=gpurun_out/gemm_tune_gfx950.txt
 rm -f $OUT

@@ -71,3 +71,61 @@ def test_bench_gpus_n_without_gpu_fails_loudly():
         pytest.skip("GPU present")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)
+
+
+def test_skewed_pair_schedule_and_group_cut(monkeypatch):
+    """TCL_SKEW, host side only: `Generator._run_groups` cuts a lone group at the chunk boundary nearest to half its frames and pairs
+    the groups; `UNetEngine.forward_pair` takes the draws for A then B and alternates the two UNet generators with A two segments ahead, so per
+    merging block the issue order is  M(A,b) .. A(A,b) | M(B,b) | F(A,b) P(A,b+1) | A(B,b) | M(A,b+1)  -- bank order A before B in every block."""
+    from types import SimpleNamespace
+    from tc_light_amd.generate import Generator
+    from tc_light_amd.unet import UNetEngine
+    log = []
+
+    class Eng:
+        def __init__(self):
+            self.tome = SimpleNamespace(begin_step=lambda Fs, size: log.append(("draws", tuple(Fs))) or [(F, [0], 0.5) for F in Fs])
+
+        def _forward_gen(self, x, Fs, Hh, Ww, t, text, cfg_pair=False, skew=False, chunks=None):
+            assert skew and chunks is not None and len(chunks) == len(Fs)
+            for b in range(3):                             # three merging blocks
+                log.append((x, "P", b)); yield "M"
+                log.append((x, "M", b)); yield "A"
+                log.append((x, "A", b)); yield "F"
+                log.append((x, "F", b))
+            return x + "-eps"
+
+    ea, eb = UNetEngine.forward_pair(Eng(), "a", [4, 4], "b", [4, 3], 8, 8, 1.0, None, cfg_pair=True)
+    assert (ea, eb) == ("a-eps", "b-eps")
+    assert log[:2] == [("draws", (4, 4)), ("draws", (4, 3))]
+    seq = [e for e in log[2:]]
+    for b in range(3):                                     # chains: A's before B's in every block; a chain is issued right behind the OTHER group's attn1
+        assert seq.index(("a", "M", b)) < seq.index(("b", "M", b))
+        assert seq[seq.index(("b", "M", b)) - 1] == ("a", "A", b)
+        if b:
+            assert seq[seq.index(("a", "M", b)) - 1] == ("b", "A", b - 1)
+        # between a chain and its own attn1 the main stream gets the other group's non-attention work
+        between = seq[seq.index(("b", "M", b)) + 1:seq.index(("b", "A", b))]
+        assert ("a", "F", b) in between
+    assert sorted(seq) == sorted((g, s, b) for g in "ab" for s in "PMAF" for b in range(3))
+
+    calls = []
+    unet = SimpleNamespace(forward_pair=lambda xa, Fa, xb, Fb, *r, **k: calls.append(("pair", Fa, Fb)) or ("ea", "eb"),
+                           forward_many=lambda x, Fs, *r, **k: calls.append(("one", Fs)) or "e")
+    gen = SimpleNamespace(unet=unet)
+    chunks = [list(range(3)), list(range(3, 19)), list(range(19, 35)), list(range(35, 40))]      # 3 + 16 + 16 + 5 frames
+    pack = lambda grp: (None, None, sum(len(c) for c in grp))
+    monkeypatch.setenv("TCL_SKEW", "1")
+    Generator._run_groups(gen, [chunks], 8, 8, 1.0, None, pack, lambda *a: None)
+    assert calls == [("pair", [3, 16], [16, 5])]
+    calls.clear()
+    Generator._run_groups(gen, [chunks[:2], chunks[2:3], chunks[3:]], 8, 8, 1.0, None, pack, lambda *a: None)     # cut -> [3] [16] [16] [5]: two pairs
+    assert calls == [("pair", [3], [16]), ("pair", [16], [5])]
+    calls.clear()
+    monkeypatch.setenv("TCL_SKEW", "cut")
+    Generator._run_groups(gen, [chunks], 8, 8, 1.0, None, pack, lambda *a: None)
+    assert calls == [("one", [3, 16]), ("one", [16, 5])]
+    calls.clear()
+    monkeypatch.setenv("TCL_SKEW", "0")
+    Generator._run_groups(gen, [chunks], 8, 8, 1.0, None, pack, lambda *a: None)
+    assert calls == [("one", [3, 16, 16, 5])]

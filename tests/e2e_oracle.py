@@ -41,8 +41,9 @@ class Recorder:
             return self._step(eps, t, x, noise=noise, **kw)
 
         def begin_step(Fs, size):
-            self._begin(Fs, size)
+            chunks = self._begin(Fs, size)
             self.draws.extend((f, r, c) for f, r, c in tome._chunks)
+            return chunks
         gen.scheduler.step, tome.begin_step = step, begin_step
 
     def finish(self):

@@ -46,6 +46,12 @@ int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, fl
  * 64x16 pixel tile, flushed once; 0 = every addend straight to global memory.  Integer (fixed-point) sums either way: same bits when W % 64 == 0,
  * the same value up to the f32 rounding of differently grouped partial sums otherwise.  Test / A-B hook (env TCL_FLOW_TILED sets the initial mode). */
 int tcl_flow_scatter_mode(int tiled);
+/* Per-frame fixed-point scale of that scatter (the reference's float grid_sample backward, utils/flow_utils.py:5-16, has no range limit; the
+ * engine's bit-reproducible integer cells do).  flow_shift[f] = min(22, 30 - ceil(log2 L_f)) with L_f = the largest number of masked-in pixels
+ * of frame f whose bicubic 4x4 window covers one pixel of frame f-1: with |mask * weight| <= 1 no 32-bit cell can overflow, however strongly the
+ * flow converges.  Call once per clip (flows / masks are constants of both stages) and pass flow_shift to the four stage entry points below.
+ * flows [N,2,h,w], masks [N,1,h,w]; scratch: (h*w + 1) int32; flow_shift: N int32 (device). */
+int tcl_flow_cell_shift(const float* flows, const float* masks, int N, int H, int W, int* scratch, int* flow_shift, hipStream_t st);
 /* Are the track ids of every frame pairwise distinct (true of get_flowid's output, utils/flow_utils.py:56-93: a pixel of frame i takes the id
  * of ONE pixel of frame i-1 or a fresh id)?  *result (device int) <- 1 / 0; scratch: K ints.  Stage 2 then accumulates codebook rows one frame
  * at a time without atomics -- bit-reproducible -- by passing ids_unique = 1 below; with 0 it falls back to float atomics (any id layout). */
@@ -61,13 +67,13 @@ size_t tcl_stage_workspace_bytes(int batch, int h, int w);
 /* Generator.exposure_align  generate.py:354-451.  exposure [N,3,4] (= eye on entry), g/m/v zero on entry;
  * aligned_out [N,3,h,w] receives OptDataset.exposure_align's result.  lr(it) = get_expon_lr_func(lr_init, lr_final,
  * max_steps = epochs*N/batch)((it / iters_per_epoch) * N / batch + it % iters_per_epoch + 1)  (generate.py:372,394). */
-int tcl_exposure_align(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* sched,
+int tcl_exposure_align(const float* edited, const float* flows, const float* masks, const int* flow_shift, int N, int H, int W, const int* sched,
                        const int* d_cat, int iters, int iters_per_epoch, int batch, int epochs, float lr_init, float lr_final, float lambda_dssim,
                        float lambda_flow, float* exposure, float* g, float* m, float* v, float* losses, float* aligned_out,
                        void* ws, hipStream_t st);
 /* Generator.unique_tensor_optimization  generate.py:453-533.  feat/g/m/v [3,K] planar, feat initialised by tcl_scatter_mean_rgb2sh;
  * images_out [N,3,h,w] (may be NULL) receives the final gather. */
-int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
+int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W,
                           size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim,
                           float lambda_flow, float lambda_tv, float* feat, float* g, float* m, float* v, float* losses,
                           float* images_out, void* ws, void* lazy_ws, hipStream_t st);
@@ -84,10 +90,10 @@ size_t tcl_stage2_lazy_workspace_bytes(size_t K, int iters);
  * for THIS caller's slots; b_glob = slots of the whole mini-batch, nvalid_glob = how many of them have frame id > 0: every mean of the
  * reference's loss runs over the global mini-batch, so the callers' partial gradients and *loss_part values simply add up.
  * g is accumulated into (+=) and must be zero (or hold other slots' partial sums) on entry; ws: tcl_stage_workspace_bytes(b_loc, h, w). */
-int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* d_cidx, int b_loc,
+int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, const int* flow_shift, int N, int H, int W, const int* d_cidx, int b_loc,
                       int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow, const float* exposure, float* g,
                       float* loss_part, void* ws, hipStream_t st);
-int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
+int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W, size_t K,
                            int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
                            float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st);
 

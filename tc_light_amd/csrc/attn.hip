@@ -24,6 +24,9 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef TCL_FLASH_PV32_DEFAULT
+#define TCL_FLASH_PV32_DEFAULT 0
+#endif
 #define KV_TILE 64
 #define V_STRIDE 72   // halves: 144 B = 9 x 16 B (odd) -> the 16-lane groups of a ds_read_b128 are conflict-free
 
@@ -119,7 +122,7 @@ __device__ __forceinline__ float xhalf_max(float v) {
 
 // (the body of k_flash for ONE block index: the kernel below calls it once, or -- the flag-gated exact pass behind the speculative kernel -- once per
 // flagged index of its stride class)
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW>
 __device__ __forceinline__ void flash_block(const int bid, const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                             _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                             int kv_div, int nqb, int* __restrict__ flags) {
@@ -137,7 +140,10 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
     // X.row1 <-> Y.row0, X.row3 <-> Y.row2 turns X into the operand of queries 0-15 and Y into that of queries 16-31, key groups in the order
     // (A, B, C, D) = keys {0-3,8-11}, {16-19,24-27}, {4-7,12-15}, {20-23,28-31} -- which the V^T panel's in-tile key permutation already
     // stores at halves 0, 16, 8, 24 of a 32-key block.
-    constexpr bool PV16 = D == 40 && LROW && DPV >= 48;
+    // PVW = 32 (round 5): head_dim 40 back on 8 MFMAs 32x32x16 over all 64 V^T rows.  The loop is bound by vector ISSUE, not by matrix cycles
+    // (tools/micro/flash_mix.hip): the 16 permlane16_swap of a wave-tile and 4 of its 12 + 6 MFMA issues cost more issue slots than the 64
+    // matrix cycles PV16 saves; the 32x32 P registers ARE the 32x32x16 B operand (the panel's in-tile key permutation absorbs the key order).
+    constexpr bool PV16 = PVW == 16 && D == 40 && LROW && DPV >= 48;
     constexpr int NT16 = 3;                                       // 16-row V^T tiles: rows 0-39 V, row 40 ones, 41-47 zero
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 stages of SSTRIDE bytes + 1 KiB dump
 
@@ -217,7 +223,7 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
 #endif
     constexpr float OFF = TCL_SPEC_OFF;
     unsigned orv = 0;                                 // SPEC: OR of the packed P registers since the last guard test
-    static_assert(!SPEC || (FOLD && PV16), "the speculative softmax is the head_dim-40 path");
+    static_assert(!SPEC || (FOLD && (PV16 || PVQ)), "the speculative softmax is the head_dim-40 path");
     auto rebase = [&](const int it, const bool first) __attribute__((always_inline)) {
         if constexpr (SPEC) {
         const _Float16* kt = (const _Float16*)(smem + (it % NSTG) * SSTRIDE);
@@ -243,11 +249,18 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
             m[qb] = mn;
             if (hl == 1) qf[qb][D / 16][0] = (_Float16)(-mn);                    // Q[q][D] lives in fragment D/16, lanes hl == 1, element 0
             if (!first) {
+                if constexpr (PV16) {
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const float aq = __shfl(alpha, (lane & 15) + 16 * qt, 64);   // this accumulator's query sits in another lane of the S^T layout
+                    for (int qt = 0; qt < 2; ++qt) {
+                        const float aq = __shfl(alpha, (lane & 15) + 16 * qt, 64);   // this accumulator's query sits in another lane of the S^T layout
 #pragma unroll
-                    for (int t = 0; t < NT16; ++t) o16[qb][qt][t] *= aq;
+                        for (int t = 0; t < NT16; ++t) o16[qb][qt][t] *= aq;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][t][r] *= alpha;           // 32x32 O^T: the query is this lane's own
                 }
             }
         }
@@ -309,16 +322,23 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
                     for (int r = 0; r < 16; ++r) pf[qb][blk][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(s[blk][r]);
                     u32x4 x = __builtin_bit_cast(u32x4, pf[qb][blk][0]), y = __builtin_bit_cast(u32x4, pf[qb][blk][1]);
                     orv |= x[0] | x[1] | x[2] | x[3] | y[0] | y[1] | y[2] | y[3];
+                    if constexpr (PV16) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
-                        x[w] = sw[0]; y[w] = sw[1];
-                    }
-                    const half8 p0 = __builtin_bit_cast(half8, x), p1 = __builtin_bit_cast(half8, y);      // queries 0-15 | 16-31
+                        for (int w = 0; w < 4; ++w) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(x[w], y[w], false, false);
+                            x[w] = sw[0]; y[w] = sw[1];
+                        }
+                        const half8 p0 = __builtin_bit_cast(half8, x), p1 = __builtin_bit_cast(half8, y);      // queries 0-15 | 16-31
 #pragma unroll
-                    for (int t = 0; t < NT16; ++t) {
-                        o16[qb][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p0, o16[qb][0][t], 0, 0, 0);
-                        o16[qb][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p1, o16[qb][1][t], 0, 0, 0);
+                        for (int t = 0; t < NT16; ++t) {
+                            o16[qb][0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p0, o16[qb][0][t], 0, 0, 0);
+                            o16[qb][1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[blk][t], p1, o16[qb][1][t], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                            for (int t = 0; t < NDT; ++t) o[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfr[blk][ss][t], pf[qb][blk][ss], o[qb][t], 0, 0, 0);
                     }
                 }
             }
@@ -508,9 +528,12 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
         // row sums (O^T row 40) that are not finite and positive: some P left the f16 range -> this block is redone by the gated exact kernel
         bool bad = false;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < QB; ++qb) {
+            if constexpr (PV16) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { const float l = __shfl(o16[qb][qt][2][0], 32 + (lane & 15), 64); bad |= !(l > 0.f && l < 3e38f); }
+                for (int qt = 0; qt < 2; ++qt) { const float l = __shfl(o16[qb][qt][2][0], 32 + (lane & 15), 64); bad |= !(l > 0.f && l < 3e38f); }
+            } else { const float l = o[qb][D / 32][4 * ((D % 32) / 8)]; bad |= hl == 0 && !(l > 0.f && l < 3e38f); }     // O^T row D, lanes hl == 0
+        }
         const int anybad = __syncthreads_or(bad);
         if (tid == 0) flags[bid] = anybad;
     }
@@ -565,7 +588,7 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW>
 __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb, int* __restrict__ flags, int nblk) {
@@ -576,13 +599,13 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
         if (flags) {
             for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
                 if (!flags[bid]) continue;
-                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
                 __syncthreads();                  // the next item re-uses the LDS ring
             }
             return;
         }
     }
-    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -812,13 +835,13 @@ static void flash_prof_drain(bool all) {
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0, int PVW = 16>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st, int* flags = nullptr, bool count = true) {
     constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     const int nqb = Tqp / (128 * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -828,7 +851,7 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     }
     const int nblk = B * H * nqb;
     const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > 512) ? 512 : nblk;      // gated exact pass: one resident round of blocks walks the flags
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC>), dim3(grid), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>), dim3(grid), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -852,6 +875,13 @@ static int launch_flash40p(const _Float16* Qp, const _Float16* Kp, const _Float1
 }
 
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+// head_dim 40: PV on 32x32x16 MFMAs (1, round 5) or on 16x16x32 MFMAs behind permlane16 swaps (0, rounds 2-4).  The V^T panel's row skew belongs to
+// the 16x16x32 fragment read, so the packing and every head_dim-40 kernel variant of a process follow the same switch (TCL_FLASH_PV=16|32).
+static int g_pv32 = -1;
+static inline bool flash_pv32() {
+    if (g_pv32 < 0) { const char* e = getenv("TCL_FLASH_PV"); g_pv32 = e ? (atoi(e) == 32) : TCL_FLASH_PV32_DEFAULT; }
+    return g_pv32 != 0;
+}
 
 extern "C" {
 
@@ -892,7 +922,7 @@ static int attention_pack(const void* q, int ldq, long qbs, const void* k, int l
         PackRows pq = {(const _Float16*)q, qbs, ldq, Tq, d, scale * 1.4426950408889634f, Qp, Tqp, DP, qc, -1};
         PackRows pk = {(const _Float16*)k, kbs, ldk, Tk, d, 1.f, Kp, Tkp, KS, kc, d == 40 ? d : -1};
         hipLaunchKernelGGL(k_pack_qkv, dim3(gq + gk + nt * Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, pq, pk, gq, gk, H, (const _Float16*)v, vbs, ldv, Tk, d, Vt,
-                           nt, DPV, d == 40 ? 1 : 0);
+                           nt, DPV, d == 40 && !flash_pv32() ? 1 : 0);
         return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
     }
     if (pack_q)
@@ -901,7 +931,7 @@ static int attention_pack(const void* q, int ldq, long qbs, const void* k, int l
     if (pack_kv) {
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(kc, 256, 2)), dim3(256), 0, st, (const _Float16*)k, kbs, ldk, Tk, H, d, 1.f, Kp, Tkp, KS, kc,
                            d == 40 ? d : -1);
-        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV, d == 40 ? 1 : 0);
+        hipLaunchKernelGGL(k_pack_vt, dim3(Tkp / 64, Bkv * H), dim3(256), (size_t)64 * (DPV + 2) * 2, st, (const _Float16*)v, vbs, ldv, Tk, H, d, Vt, Tkp / 64, DPV, d == 40 && !flash_pv32() ? 1 : 0);
     }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -936,6 +966,16 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (d == 40 && var40 == 4) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 40 && var40 == 3) return launch_flash<40, 48, 64, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40 && flash_pv32()) {
+        if (qb2 && var40 == 0) {
+            int* flags = (int*)((char*)ws_q + (((size_t)B * H * Tqp * DP * 2 + 255) / 256) * 256);
+            int rc = launch_flash<40, 48, 64, 2, 4, 2, 0, 1, 32>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags);
+            if (rc == TCL_OK) rc = launch_flash<40, 48, 64, 2, 4, 2, 0, 0, 32>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags, false);
+            return rc;
+        }
+        return qb2 && var40 != 1 ? launch_flash<40, 48, 64, 2, 4, 2, 0, 0, 32>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                                 : launch_flash<40, 48, 64, 1, 2, 1, 4, 0, 32>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    }
     if (d == 40 && qb2 && var40 == 0) {
         // speculative softmax (no row maxima in the loop), then the exact kernel over the blocks that flagged an f16 overflow of P (normally none:
         // its blocks read one flag and leave)

@@ -30,9 +30,15 @@
 typedef long long fx_t;
 #define FX_SSIM 1073741824.f            // 2^30: per-block sums of SSIM values, |.| <= TW*TH
 #define FX_ACC 1048576.f                // 2^20: loss sums over a mini-batch (<= ~1e8)
-#define FX_FLOW 4194304.f               // 2^22: mask * bicubic weights landing on one pixel of the previous frame, in a 32-BIT cell (round 4; 2^32 in
-                                        // 64-bit cells before): resolution 2.4e-7 per contribution, range +-512 -- a cell receives ~16 weights of |w| <= 1
-                                        // from a smooth flow; 32-bit integer atomics run ~2x the rate of 64-bit ones and gpre halves (memset, reads)
+#define FX_FLOW_SHIFT 22                // mask * bicubic weights landing on one pixel of the previous frame, in a 32-BIT cell (round 4; 2^32 in 64-bit
+                                        // cells before): at 2^22 per unit the resolution is 2.4e-7 per contribution and the range +-512 -- a cell receives
+                                        // ~16 weights of |w| <= 1 from a smooth flow; 32-bit integer atomics run ~2x the rate of 64-bit ones and gpre
+                                        // halves (memset, reads).  Round 5: the scale is PER FRAME, 2^flow_shift[f] with flow_shift[f] =
+                                        // min(22, 30 - ceil(log2 L_f)), L_f = the largest number of masked-in pixels of frame f whose 4x4 tap window
+                                        // covers one cell (tcl_flow_cell_shift, once per clip: flows and masks do not change during the optimisation).
+                                        // |mask * weight| <= 1 per pixel and cell, so no cell -- LDS window or global -- can leave the 32-bit range
+                                        // however strongly a flow converges (a zoom-out, a degenerate flow net output): frames past 512 pixels per cell
+                                        // trade resolution for range instead of wrapping silently.  Smooth flows get 22 everywhere: round 4's bits.
 typedef int fxq_t;
 #define FX_EXPO 281474976710656.f       // 2^48: exposure gradient components (sums of image * pixel gradient)
 __device__ __forceinline__ void fx_add(fx_t* p, float v, float scale) {
@@ -117,9 +123,11 @@ __global__ void k_apply_exposure(const float* __restrict__ src, const int* __res
 // d(loss)/dM of cat row j from the gradient of its clamped output -> efx[j][12] (fixed point; ordered add into grad_expo by k_expo_fin).
 // Rows j >= b are the "previous frame" images: their gradient is the flow term's scatter, held in fixed point (gpre, see k_flow_loss).
 __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ expo,
-                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, int b, fx_t* __restrict__ efx, int P) {
+                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, const int* __restrict__ flow_shift,
+                               int b, fx_t* __restrict__ efx, int P) {
     __shared__ float red[16];
     const int j = blockIdx.y, f = idx[j];
+    if (j >= b) pre_scale = __builtin_ldexpf(pre_scale, -flow_shift[idx[j - b]]);      // the scatter of slot j - b ran at its current frame's scale
     const float* M = expo + (size_t)f * 12;
     float m[12], acc[12];
 #pragma unroll
@@ -165,9 +173,10 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
 // ATOMIC == true (ids that repeat inside a frame): all rows in one launch, float atomics, order not reproducible.
 template <bool ATOMIC>
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, int b, int j0,
-                               float* __restrict__ gfeat, int P, size_t K) {
+                               const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, const int* __restrict__ flow_shift,
+                               int b, int j0, float* __restrict__ gfeat, int P, size_t K) {
     const int j = j0 + blockIdx.y, f = fidx[j];
+    if (j >= b) pre_scale = __builtin_ldexpf(pre_scale, -flow_shift[fidx[j - b]]);
     const int* iv = inv + (size_t)f * P;
     const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
     const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
@@ -376,10 +385,10 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
 #define FT_SL 5
 #define FT_WX (FT_W + 3 + FT_SL)
 #define FT_WY (FT_H + 3 + FT_SL)
-struct FlowWin { int* cells; int x0, y0; };
+struct FlowWin { int* cells; int x0, y0; float fx; };       // fx: this frame's fixed-point scale 2^flow_shift[f]
 template <bool TILED>
 __device__ __forceinline__ void flow_sink(const FlowWin& w, fxq_t* __restrict__ gp, int c, int P, int W, int yy, int xx, float v) {
-    const int q = __float2int_rn(v * FX_FLOW);
+    const int q = __float2int_rn(v * w.fx);
     if (TILED) {
         const int lx = xx - w.x0, ly = yy - w.y0;
         if ((unsigned)lx < (unsigned)FT_WX && (unsigned)ly < (unsigned)FT_WY) { atomicAdd(w.cells + (c * FT_WY + ly) * FT_WX + lx, q); return; }
@@ -454,7 +463,7 @@ __device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
                                                    const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
-                                                   fxq_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x) {
+                                                   fxq_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x, const int* __restrict__ flow_shift) {
     __shared__ float red[16];
     __shared__ int wmin[2];
     extern __shared__ __attribute__((aligned(16))) int fwin[];
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat
     const float* fl = flows + (size_t)f * 2 * P; const float* mk = masks + (size_t)f * P;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
-    FlowWin win = {fwin, 0, 0};
+    FlowWin win = {fwin, 0, 0, __builtin_ldexpf(1.f, flow_shift[f])};
     if (!TILED) {
         // every lane of a wave runs the same trip count (the shuffles need all 64 lanes); lanes past the image are `live == false`
         for (int p0 = blockIdx.x * blockDim.x; p0 < P; p0 += gridDim.x * blockDim.x) {
@@ -507,14 +516,49 @@ __global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat
     float r = block_sum(s, red);
     if (threadIdx.x == 0) fx_add(acc + ((blockIdx.x + blockIdx.y) & (ACC_SLOTS - 1)) * 4 + 3, r, FX_ACC);
 }
+// ---- per-frame cell load of the flow scatter -> flow_shift[f] (FX_FLOW_SHIFT comment).  A pixel with tap origin (x0, y0) touches the cells
+// [x0, x0 + 3] x [y0, y0 + 3], so the number of masked-in pixels reaching cell (cx, cy) is the 4x4 box sum of the ORIGIN histogram over
+// [cx - 3, cx] x [cy - 3, cy]: one integer atomic per pixel, then one box sum per cell.  Origins left of / above the image are clamped to 0
+// (their window then still covers every in-image cell they touch: the bound only grows).
+__global__ void k_flow_origin_hist(const float* __restrict__ fl, const float* __restrict__ mk, int H, int W, int* __restrict__ hist) {
+    const int P = H * W;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        if (!(mk[p] != 0.f)) continue;
+        const int y = p / W, x = p - y * W;
+        const Tap t = make_tap(fl[p], fl[P + p], x, y, W, H);
+        if (t.x0 >= W || t.y0 >= H || t.x0 + 3 < 0 || t.y0 + 3 < 0) continue;      // no tap inside the image
+        atomicAdd(hist + max(t.y0, 0) * W + max(t.x0, 0), 1);
+    }
+}
+__global__ void k_flow_cell_load(int* __restrict__ hist_max, const int* __restrict__ hist, int H, int W) {
+    __shared__ int red[4];
+    int mx = 0;
+    const int P = H * W;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int cy = p / W, cx = p - cy * W;
+        int s = 0;
+        for (int j = 0; j < 4; ++j) { const int yy = cy - j; if (yy < 0) break;
+            for (int i = 0; i < 4; ++i) { const int xx = cx - i; if (xx < 0) break; s += hist[yy * W + xx]; } }
+        mx = max(mx, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(hist_max, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+__global__ void k_flow_shift_set(const int* __restrict__ load, int* __restrict__ shift) {
+    const int L = max(*load, 1);
+    int lg = 0; while ((1 << lg) < L) ++lg;                 // ceil(log2 L)
+    *shift = min(FX_FLOW_SHIFT, 30 - lg);
+}
 static int g_flow_tiled = -1;
 static void launch_flow_loss(const float* cat, const int* cidx, const float* flows, const float* masks, int b, int H, int W, float fscale, float* gimg,
-                             fxq_t* gpre, fx_t* acc, dim3 untiled_grid, hipStream_t st) {
+                             fxq_t* gpre, fx_t* acc, dim3 untiled_grid, const int* flow_shift, hipStream_t st) {
     if (g_flow_tiled < 0) g_flow_tiled = getenv("TCL_FLOW_TILED") ? atoi(getenv("TCL_FLOW_TILED")) : 1;      // A/B hook: 0 = global atomics only
     if (g_flow_tiled) {
         const int tx = cdiv(W, FT_W), ty = cdiv(H, FT_H);
-        hipLaunchKernelGGL(k_flow_loss<true>, dim3(tx * ty, b), dim3(256), (size_t)3 * FT_WY * FT_WX * 4, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, tx);
-    } else hipLaunchKernelGGL(k_flow_loss<false>, untiled_grid, dim3(256), 0, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, 0);
+        hipLaunchKernelGGL(k_flow_loss<true>, dim3(tx * ty, b), dim3(256), (size_t)3 * FT_WY * FT_WX * 4, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, tx, flow_shift);
+    } else hipLaunchKernelGGL(k_flow_loss<false>, untiled_grid, dim3(256), 0, st, cat, cidx, flows, masks, b, H, W, fscale, gimg, gpre, acc, 0, flow_shift);
 }
 // loss = w_photo*(c_l1*acc0 + msssim_term) + w_flow*acc3/cnt_flow + tv ; acc reset for the next iteration
 __global__ void k_loss_finalize(fx_t* acc, const float* ms_term, float w_photo, float c_l1, float w_flow, float inv_cnt_flow,
@@ -642,6 +686,18 @@ static inline int pooled(int s) { return (s + 2 * (s & 1) - 2) / 2 + 1; }
 extern "C" {
 
 int tcl_flow_scatter_mode(int tiled) { g_flow_tiled = tiled; return TCL_OK; }
+
+int tcl_flow_cell_shift(const float* flows, const float* masks, int N, int H, int W, int* scratch, int* flow_shift, hipStream_t st) {
+    TCL_CHECK_ARG(flows && masks && scratch && flow_shift && N > 0 && H > 3 && W > 3);
+    const size_t P = (size_t)H * W;
+    for (int f = 0; f < N; ++f) {                             // (frame 0 is never a flow target: its entry is computed like any other)
+        if (hipMemsetAsync(scratch, 0, (P + 1) * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        hipLaunchKernelGGL(k_flow_origin_hist, pgrid(P, 1), dim3(256), 0, st, flows + (size_t)f * 2 * P, masks + (size_t)f * P, H, W, scratch);
+        hipLaunchKernelGGL(k_flow_cell_load, pgrid(P, 1), dim3(256), 0, st, scratch + P, scratch, H, W);
+        hipLaunchKernelGGL(k_flow_shift_set, dim3(1), dim3(1), 0, st, scratch + P, flow_shift + f);
+    }
+    TCL_LAUNCH_RET();
+}
 
 
 int tcl_warp_flow_fwd(const float* img, const float* flow, float* out, int n, int c, int h, int w, int flow_c, hipStream_t st) {
@@ -806,10 +862,10 @@ static double expon_lr(int step, double lr_init, double lr_final, int max_steps)
 // d_cidx (device) int32 [2*b_loc]: [cur(b_loc) | max(cur-1, 0)(b_loc)] -- THIS caller's slots of the mini-batch.  b_glob / nvalid_glob:
 // slots and slots with idx > 0 of the WHOLE mini-batch: every mean of the loss (generate.py:413-427, :507-520) runs over the global batch,
 // so partial losses / gradients of the ranks simply add up.  g is accumulated into (+=); *loss_part receives this caller's share of the loss.
-int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* d_cidx, int b_loc,
+int tcl_exposure_grad(const float* edited, const float* flows, const float* masks, const int* flow_shift, int N, int H, int W, const int* d_cidx, int b_loc,
                       int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow, const float* exposure, float* g,
                       float* loss_part, void* ws, hipStream_t st) {
-    TCL_CHECK_ARG(edited && flows && masks && d_cidx && exposure && g && loss_part && ws);
+    TCL_CHECK_ARG(edited && flows && masks && flow_shift && d_cidx && exposure && g && loss_part && ws);
     TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160);
     StageWs S = carve_stage((char*)ws, b_loc, H, W);
     const size_t P = (size_t)H * W;
@@ -826,19 +882,19 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
     if (hipMemsetAsync(S.efx, 0, (size_t)2 * b * 12 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
-    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), st);
+    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), flow_shift, st);
     // 64 blocks per row (each block ends in 12 block-wide sums + 12 atomics: with the P / 1024-pixel blocks of the other kernels this was the
     // slowest kernel of stage 1), partial sums in fixed point, rows added to the gradient in order
-    hipLaunchKernelGGL(k_exposure_bwd, dim3(64, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gimg, S.gpre, fscale / FX_FLOW, b, S.efx, (int)P);
+    hipLaunchKernelGGL(k_exposure_bwd, dim3(64, 2 * b), dim3(256), 0, st, edited, S.cidx, exposure, S.gimg, S.gpre, fscale, flow_shift, b, S.efx, (int)P);
     hipLaunchKernelGGL(k_expo_fin, dim3(1), dim3(64), 0, st, S.efx, S.cidx, 2 * b, g);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, c_l1, lambda_flow, inv_cnt, 0.f, 0.f, loss_part);
     TCL_LAUNCH_RET();
 }
 
-int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W, size_t K,
+int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W, size_t K,
                            int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
                            float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st) {
-    TCL_CHECK_ARG(target && flows && masks && unq_inv && d_cidx && feat && g && loss_part && ws);
+    TCL_CHECK_ARG(target && flows && masks && flow_shift && unq_inv && d_cidx && feat && g && loss_part && ws);
     TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_loc <= 64 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160 && K > 0);
     StageWs S = carve_stage((char*)ws, b_loc, H, W);
     const size_t P = (size_t)H * W;
@@ -855,11 +911,11 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     if (hipMemsetAsync(S.gpre, 0, (size_t)b * 3 * P * sizeof(fxq_t), st) != hipSuccess) return TCL_ELAUNCH;
     float inv_cnt = nvalid_glob ? 1.f / ((float)nvalid_glob * 3 * P) : 0.f;
     const float fscale = lambda_flow * inv_cnt;
-    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), st);
+    launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), flow_shift, st);
     if (ids_unique)          // one cat row per launch, in order: conflict-free read-modify-write of the rows' gradients, no atomics
         for (int j = 0; j < 2 * b; ++j)
-            hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale / FX_FLOW, b, j, g, (int)P, K);
-    else hipLaunchKernelGGL(k_codebook_bwd<true>, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale / FX_FLOW, b, 0, g, (int)P, K);
+            hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, j, g, (int)P, K);
+    else hipLaunchKernelGGL(k_codebook_bwd<true>, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, 0, g, (int)P, K);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, loss_part);
     TCL_LAUNCH_RET();
 }
@@ -867,11 +923,11 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
 // Stage 1 (generate.py:354-451).  sched: host int32 [iters][batch] frame ids, -1 pads a short batch;
 // d_cat: packed cat indices on the device.  exposure/m/v/g: [N,3,4] device (exposure = eye, others 0 on entry).
 // losses: device float [iters].  On return (stream order) `aligned_out` holds the aligned frames.
-int tcl_exposure_align(const float* edited, const float* flows, const float* masks, int N, int H, int W, const int* sched,
+int tcl_exposure_align(const float* edited, const float* flows, const float* masks, const int* flow_shift, int N, int H, int W, const int* sched,
                        const int* d_cat, int iters, int iters_per_epoch, int batch, int epochs, float lr_init, float lr_final, float lambda_dssim,
                        float lambda_flow, float* exposure, float* g, float* m, float* v, float* losses, float* aligned_out,
                        void* ws, hipStream_t st) {
-    TCL_CHECK_ARG(edited && flows && masks && sched && d_cat && exposure && g && m && v && losses && aligned_out && ws);
+    TCL_CHECK_ARG(edited && flows && masks && flow_shift && sched && d_cat && exposure && g && m && v && losses && aligned_out && ws);
     TCL_CHECK_ARG(N > 0 && batch > 0 && iters > 0 && epochs > 0 && iters_per_epoch > 0 && H > 160 && W > 160);
     const size_t P = (size_t)H * W;
     const int total_iters = epochs * N / batch, per_epoch = iters_per_epoch;
@@ -882,7 +938,7 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
         TCL_CHECK_ARG(b > 0);
         int epoch = it / per_epoch, i = it % per_epoch;
         float lr = (float)expon_lr(epoch * N / batch + i + 1, lr_init, lr_final, total_iters);
-        int rc = tcl_exposure_grad(edited, flows, masks, N, H, W, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim, lambda_flow,
+        int rc = tcl_exposure_grad(edited, flows, masks, flow_shift, N, H, W, d_cat + (size_t)it * 2 * batch, b, b, nvalid, lambda_dssim, lambda_flow,
                                    exposure, g, losses + it, ws, st);
         if (rc) return rc;
         rc = tcl_adam_step(exposure, g, m, v, (size_t)N * 12, lr, 0.9f, 0.999f, 1e-8f, it + 1, st);
@@ -893,11 +949,11 @@ int tcl_exposure_align(const float* edited, const float* flows, const float* mas
 }
 
 // Stage 2 (generate.py:453-533).  feat/g/m/v: channel-planar [3,K] device (feat initialised by tcl_scatter_mean_rgb2sh, others 0).
-int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* unq_inv, int N, int H, int W,
+int tcl_unique_tensor_opt(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W,
                           size_t K, int ids_unique, const int* sched, const int* d_cat, int iters, int batch, float feature_lr, float lambda_dssim, float lambda_flow,
                           float lambda_tv, float* feat, float* g, float* m, float* v, float* losses, float* images_out, void* ws,
                           void* lazy_ws, hipStream_t st) {
-    TCL_CHECK_ARG(target && flows && masks && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
+    TCL_CHECK_ARG(target && flows && masks && flow_shift && unq_inv && feat && g && m && v && losses && ws && (iters == 0 || (sched && d_cat)));
     TCL_CHECK_ARG(N > 0 && batch > 0 && batch <= 64 && iters >= 0 && H > 160 && W > 160 && K > 0);
     const size_t P = (size_t)H * W;
     const float lr = feature_lr * (float)batch / (float)N;
@@ -921,7 +977,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         if (lazy)       // the mini-batch's rows catch up with the steps they skipped (1 .. it) before they are gathered
             hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,
                                1e-15f, bc1, bc2);
-        int rc = tcl_unique_tensor_grad(target, flows, masks, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
+        int rc = tcl_unique_tensor_grad(target, flows, masks, flow_shift, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
                                         lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
         if (rc) return rc;
         if (lazy) {

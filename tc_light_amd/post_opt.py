@@ -110,6 +110,19 @@ class OptDataset:
         if self.edited_images.max() > 1:
             self.edited_images = self.edited_images / 255.0
         self.device, self.dtype = device, dtype
+        self._flow_shift = None
+
+    @property
+    def flow_shift(self):
+        """int32 [N] on the device: per-frame fixed-point exponent of the flow term's gradient scatter (csrc/path2.hip FX_FLOW_SHIFT), from the
+        frames' flows and masks -- computed on first use, once per clip."""
+        if self._flow_shift is None:
+            n, _, h, w = self.past_flows.shape
+            dev = self.past_flows.device
+            self._flow_shift = torch.empty(n, dtype=torch.int32, device=dev)
+            scratch = torch.empty(h * w + 1, dtype=torch.int32, device=dev)
+            lib().tcl_flow_cell_shift(self.past_flows, self.mask_bwd, n, h, w, scratch, self._flow_shift, stream())
+        return self._flow_shift
 
     def __len__(self):
         return len(self.edited_images)
@@ -175,7 +188,7 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
         g, m, v = (torch.zeros_like(expo) for _ in range(3))
         losses = torch.zeros(len(sched), device=dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
-        L.tcl_exposure_align(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, sched.ctypes.data, d_cat, len(sched),
+        L.tcl_exposure_align(ed, dataset.past_flows, dataset.mask_bwd, dataset.flow_shift, n, h, w, sched.ctypes.data, d_cat, len(sched),
                              iters_per_epoch, batch_size, epochs, lr_init, lr_final, lambda_dssim, lambda_flow, expo, g, m, v, losses,
                              out, ws, stream())
     else:
@@ -183,11 +196,12 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
         from .parallel import distributed_adam_loop
         lcat, bmax = _local_cat(sched, dist.rank, dist.world, dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(bmax, h, w), dtype=torch.uint8, device=dev)
+        fsh = dataset.flow_shift
         total_iters = epochs * n // batch_size
         g = torch.zeros(n * 12, device=dev)
 
         def grad_fn(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
-            L.tcl_exposure_grad(ed, dataset.past_flows, dataset.mask_bwd, n, h, w, lcat[it], len(slots), b_glob, nvalid, lambda_dssim,
+            L.tcl_exposure_grad(ed, dataset.past_flows, dataset.mask_bwd, fsh, n, h, w, lcat[it], len(slots), b_glob, nvalid, lambda_dssim,
                                 lambda_flow, p_full, g_full, loss_out, ws, stream())
 
         def adam_fn(it, p, gg, m, v):
@@ -242,7 +256,7 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
         lazy = os.environ.get("TCL_ADAM_LAZY", "auto")
         use_lazy = uniq and len(sched) > 0 and (lazy == "1" or (lazy == "auto" and k > 3 * 2 * batch_size * h * w))
         lws = torch.empty(L.tcl_stage2_lazy_workspace_bytes(k, len(sched)), dtype=torch.uint8, device=dev) if use_lazy else 0
-        L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, uniq, sched.ctypes.data, d_cat,
+        L.tcl_unique_tensor_opt(ed, dataset.past_flows, dataset.mask_bwd, dataset.flow_shift, inv, n, h, w, k, uniq, sched.ctypes.data, d_cat,
                                 len(sched), batch_size, feature_lr, lambda_dssim, lambda_flow, lambda_tv, feat, g, m, v,
                                 losses, out, ws, lws, stream())
         losses = losses[:len(sched)]
@@ -250,11 +264,12 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
         from .parallel import distributed_adam_loop
         lcat, bmax = _local_cat(sched, dist.rank, dist.world, dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(bmax, h, w), dtype=torch.uint8, device=dev)
+        fsh = dataset.flow_shift
         g = torch.zeros(npad, device=dev)
         lr = feature_lr * batch_size / n                # generate.py:474
 
         def grad_fn(it, slots, b_glob, nvalid, p_full, g_full, loss_out):
-            L.tcl_unique_tensor_grad(ed, dataset.past_flows, dataset.mask_bwd, inv, n, h, w, k, uniq, lcat[it], len(slots), b_glob, nvalid,
+            L.tcl_unique_tensor_grad(ed, dataset.past_flows, dataset.mask_bwd, fsh, inv, n, h, w, k, uniq, lcat[it], len(slots), b_glob, nvalid,
                                      lambda_dssim, lambda_flow, lambda_tv, p_full, g_full, loss_out, ws, stream())
 
         def adam_fn(it, p, gg, m, v):

@@ -445,7 +445,7 @@ def test_config5_stage2_full_size_properties():
     cat = torch.from_numpy(np.concatenate([batch[0], np.maximum(batch[0] - 1, 0)]).astype(np.int32)).cuda()
     ws = torch.empty(L.tcl_stage_workspace_bytes(16, h, w), dtype=torch.uint8, device="cuda")
     lp = torch.zeros(1, device="cuda")
-    L.tcl_unique_tensor_grad(ds.edited_images, flows, masks, inv, n, h, w, k, 1, cat, 16, 16, 15, 0.2, 0.8, 0.05, feat, gbuf, lp, ws, stream())
+    L.tcl_unique_tensor_grad(ds.edited_images, flows, masks, ds.flow_shift, inv, n, h, w, k, 1, cat, 16, 16, 15, 0.2, 0.8, 0.05, feat, gbuf, lp, ws, stream())
     L.tcl_adam_step(feat, gbuf, m, v, 3 * k, lr, 0.9, 0.999, 1e-15, 1, stream())
     assert abs(float(lp) - float(l1[0])) < 2e-5 * abs(float(l1[0]))
     d = (feat - feat1).abs()

@@ -171,6 +171,53 @@ def test_flow_scatter_lds_window_equals_global(ops):
                 assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0), (name, h, w)
 
 
+def test_flow_scatter_converging_flow_does_not_wrap(ops):
+    """the flow term's pre-image gradient lives in 32-bit fixed-point cells.  At round 4's fixed scale 2^22 a cell held +-512, and a flow
+    that sends more than 512 masked-in pixels to one target pixel wrapped silently (the reference's float grid_sample backward has no such limit).
+    The scale is per frame now (tcl_flow_cell_shift: 2^min(22, 30 - ceil(log2(pixels per cell)))): on a clip whose frame 2 COLLAPSES onto one point
+    of frame 1 (49 152 pixels per cell) and whose frame 3 zooms out 6x, the stage-1 gradient must agree with the oracle's autograd gradient, and
+    frames with smooth flows must keep the full 22 bits."""
+    from oracle import path2 as O
+    from tc_light_amd.lib import lib, stream
+    L = lib()
+    n, h, w = 5, 192, 256
+    d = synth.video_clip(n, h, w, seed=41, shift=(1.7, -0.9))
+    fl = d["past_flows"].clone()
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    g = torch.Generator().manual_seed(4)
+    fl[2, 0] = 100.3 - xs + 0.4 * torch.rand(h, w, generator=g)          # every pixel of frame 2 samples frame 1 around (100.3, 77.6)
+    fl[2, 1] = 77.6 - ys + 0.4 * torch.rand(h, w, generator=g)
+    fl[3, 0] = (xs - w / 2) / 6 + w / 2 - xs                                # zoom-out 6x: ~36 x 16 = 576 windows per cell
+    fl[3, 1] = (ys - h / 2) / 6 + h / 2 - ys
+    mk = torch.ones_like(d["masks"])
+    ds = ops.OptDataset(d["edited"], fl, mk, device="cuda")
+    sh = ds.flow_shift.cpu().tolist()
+    assert sh[1] == 22 and sh[4] == 22, sh                                   # smooth flows: round 4's resolution
+    assert sh[2] <= 30 - 16 + 1 and sh[2] >= 30 - 17, sh                   # 49 152 windows on the collapse point's cells
+    assert 30 - 11 <= sh[3] <= 30 - 9, sh
+    expo = (torch.eye(3, 4)[None].repeat(n, 1, 1) + 0.03 * torch.randn(n, 3, 4, generator=g)).contiguous()
+    idx = torch.tensor([2, 3, 1, 4])
+    cat = torch.cat([idx, (idx - 1).clamp(min=0)]).to(torch.int32).cuda()
+    gbuf = torch.zeros(n * 12, device="cuda")
+    lp = torch.zeros(1, device="cuda")
+    ws = torch.empty(L.tcl_stage_workspace_bytes(4, h, w), dtype=torch.uint8, device="cuda")
+    for mode in (1, 0):                                                       # LDS-window route and the all-global route
+        gbuf.zero_()
+        try:
+            L.tcl_flow_scatter_mode(mode)
+            L.tcl_exposure_grad(ds.edited_images, ds.past_flows, ds.mask_bwd, ds.flow_shift, n, h, w, cat, 4, 4, 4, 0.2, 0.8, expo.cuda(), gbuf, lp, ws, stream())
+            torch.cuda.synchronize()
+        finally:
+            L.tcl_flow_scatter_mode(1)
+        eo = expo.clone().requires_grad_(True)
+        loss, _, _ = O.stage1_loss(eo, d["edited"], idx, fl, mk)
+        (go,) = torch.autograd.grad(loss, eo)
+        ge = gbuf.cpu().view(n, 3, 4)
+        assert abs(float(lp) - float(loss)) < 5e-5 * abs(float(loss)), (float(lp), float(loss))
+        err = (ge - go).abs().max().item() / go.abs().max().item()
+        assert err < 2e-3, (mode, err, ge[1], go[1])                        # (frame 1 = the collapse target carries the largest entries)
+
+
 def test_stage2_lazy_adam_equals_dense(ops, monkeypatch):
     """The reference's Adam over the codebook is dense (every row moves every iteration through its momentum).  The lazy schedule only visits
     the rows of the mini-batch's frames and replays the gradient-free steps a row skipped right before it is needed; it must reproduce the dense

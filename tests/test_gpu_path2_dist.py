@@ -38,6 +38,7 @@ def test_partial_gradients_add_up():
     ed, fl, mk = (d[x].to(dev).contiguous() for x in ("edited", "past_flows", "masks"))
     inv = inv.to(device=dev, dtype=torch.int32)
     row = [3, 0, 4, 1, 2]
+    fsh = P.OptDataset(d["edited"], d["past_flows"], d["masks"], device=dev).flow_shift
     feat = torch.empty(3, k, device=dev)
     L.tcl_scatter_mean_rgb2sh(ed, inv, feat, torch.empty(k, device=dev), n, h, w, k, 1, stream())
     expo = (torch.eye(3, 4, device=dev)[None].repeat(n, 1, 1) + 0.02 * torch.randn(n, 3, 4, device=dev)).contiguous()
@@ -50,9 +51,9 @@ def test_partial_gradients_add_up():
             cat = torch.tensor(slots + [max(s - 1, 0) for s in slots], dtype=torch.int32, device=dev)
             ws = torch.empty(L.tcl_stage_workspace_bytes(len(slots), h, w), dtype=torch.uint8, device=dev)
             if stage == 2:
-                L.tcl_unique_tensor_grad(ed, fl, mk, inv, n, h, w, k, 1, cat, len(slots), b_glob, nvalid, 0.2, 0.8, 0.05, feat, g, loss[r:r + 1], ws, stream())
+                L.tcl_unique_tensor_grad(ed, fl, mk, fsh, inv, n, h, w, k, 1, cat, len(slots), b_glob, nvalid, 0.2, 0.8, 0.05, feat, g, loss[r:r + 1], ws, stream())
             else:
-                L.tcl_exposure_grad(ed, fl, mk, n, h, w, cat, len(slots), b_glob, nvalid, 0.2, 0.8, expo, g, loss[r:r + 1], ws, stream())
+                L.tcl_exposure_grad(ed, fl, mk, fsh, n, h, w, cat, len(slots), b_glob, nvalid, 0.2, 0.8, expo, g, loss[r:r + 1], ws, stream())
         return g.cpu(), float(loss.sum())
 
     for stage in (1, 2):

@@ -13,8 +13,13 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 #define PERM8 asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %0, %3\n v_permlane16_swap_b32 %1, %2\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
 #define MF32x6 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0); s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0); s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s0, 0, 0, 0); s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, s1, 0, 0, 0);
 #define MF16x6 o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o0, 0, 0, 0); o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o1, 0, 0, 0); o2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o2, 0, 0, 0); o3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o3, 0, 0, 0); o4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o4, 0, 0, 0); o5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, o5, 0, 0, 0);
+#define OR8 asm volatile("v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %1, %1, %2, %3\n v_or3_b32 %2, %2, %3, %0\n v_or3_b32 %3, %3, %0, %1\n v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %1, %1, %2, %3\n v_or3_b32 %2, %2, %3, %0\n v_or3_b32 %3, %3, %0, %1" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+#define MF32x8 p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p1, 0, 0, 0); p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p1, 0, 0, 0); p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p1, 0, 0, 0); p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, p1, 0, 0, 0);
 // MODE 0: full mix, phases in program order   1: without the maxima   2: without exp   3: MFMAs only   4: vector part only
-// MODE 5: full mix, vector work interleaved between the MFMAs (one MFMA, then ~1/18 of the vector work)
+// MODE 6 (round 5): the speculative kernel's mix as it stands -- no maxima, 8 v_or3 for the guard, PV on 12 MFMA 16x16x32 behind 8 permlane16_swap
+// MODE 7 (round 5): the same with PV on 8 MFMA 32x32x16 over 64 V^T rows and NO lane exchange (the S^T accumulator's key order is matched by the
+//                   V^T panel's in-tile key permutation): 14 MFMA issues instead of 18, 448 instead of 384 matrix cycles, no permlane
+// MODE 8: MODE 7 without the guard ORs
 template <int MODE>
 __global__ void k(unsigned long long* out, float seed) {
     float a0 = seed + threadIdx.x, a1 = a0 * 1.1f, a2 = a0 * 1.2f, a3 = a0 * 1.3f, a4 = a0 * 1.4f, a5 = a0 * 1.5f, a6 = a0 * 1.6f, a7 = a0 * 1.7f;
@@ -22,9 +27,16 @@ __global__ void k(unsigned long long* out, float seed) {
     half8 hv = {1, 2, 3, 4, 5, 6, 7, 8};
     float16v s0 = {0}, s1 = {0};
     float4v o0 = {0}, o1 = {0}, o2 = {0}, o3 = {0}, o4 = {0}, o5 = {0};
+    float16v p0 = {0}, p1 = {0};
     __syncthreads();
     const unsigned long long t0 = clock64();
     for (int lap = 0; lap < 128; ++lap) {      // one lap = one 32-query block x one 64-key tile
+        if (MODE >= 6) {
+            MF32x6 EXP8 EXP8 EXP8 EXP8 CVT8 CVT8
+            if (MODE != 8) { OR8 }
+            if (MODE == 6) { PERM8 MF16x6 MF16x6 } else { MF32x8 }
+            continue;
+        }
         if (MODE != 4) { MF32x6 }
         if (MODE != 1 && MODE != 3) { MAX8 MAX8 MAX8 }
         if (MODE != 2 && MODE != 3) { EXP8 EXP8 EXP8 EXP8 }
@@ -32,7 +44,7 @@ __global__ void k(unsigned long long* out, float seed) {
         if (MODE != 4) { MF16x6 MF16x6 }
     }
     const unsigned long long t1 = clock64();
-    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3) + s0[0] + s1[1] + o0[0] + o1[0] + o2[0] + o3[0] + o4[0] + o5[0];
+    float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3) + s0[0] + s1[1] + o0[0] + o1[0] + o2[0] + o3[0] + o4[0] + o5[0] + p0[0] + p1[0];
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { atomicMax(out, t1 - t0); out[1] = (unsigned long long)sink; }
 }
 template <int MODE> void run(const char* name, unsigned long long* d) {
@@ -41,12 +53,13 @@ template <int MODE> void run(const char* name, unsigned long long* d) {
         hipMemset(d, 0, 16);
         hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * w), 0, 0, d, 1.0f);
         unsigned long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
-        printf("%-40s %d wave(s)/SIMD: %7.0f cycles per lap of all the SIMD's waves (%5.0f per wave-lap; matrix pipe 384 per wave-lap -> %4.1f %% busy)\n", name, w,
-               (double)h[0] / 128.0, (double)h[0] / 128.0 / w, 100.0 * 384.0 * w / ((double)h[0] / 128.0) * (MODE == 4 ? 0 : 1));
+        printf("%-40s %d wave(s)/SIMD: %7.0f cycles per lap of all the SIMD's waves (%5.0f per wave-lap; matrix pipe %d per wave-lap -> %4.1f %% busy)\n", name, w,
+               (double)h[0] / 128.0, (double)h[0] / 128.0 / w, MODE >= 7 ? 448 : 384, 100.0 * (MODE >= 7 ? 448.0 : 384.0) * w / ((double)h[0] / 128.0) * (MODE == 4 ? 0 : 1));
     }
 }
 int main() {
     unsigned long long* d; hipMalloc(&d, 16);
     run<0>("full mix", d); run<1>("without max", d); run<2>("without exp", d); run<3>("MFMAs only", d); run<4>("vector part only", d);
+    run<6>("speculative mix (PV 16x16x32 + swaps)", d); run<7>("speculative mix, PV 32x32x16, no swaps", d); run<8>("  ... without the guard ORs", d);
     return 0;
 }

@@ -467,7 +467,7 @@ def main():
     dt = d.max_float(time.perf_counter() - t0, dev)
     assert torch.isfinite(out).all(), "non-finite output"
     flops_pass, flops_exec = unet.flops, unet.flops_executed
-    coll = {k: dict(v) for k, v in d.stats.items()}
+    coll = {k: dict(v) for k, v in d.collect_stats().items()}       # (event pairs recorded inside the pass, resolved here: no synchronise in the timed region)
     if a.save_gemm_table and rank == 0:
         lib().tcl_gemm_tune_save(a.save_gemm_table)
 
@@ -495,7 +495,8 @@ def main():
     per_rank = None
     if world > 1:
         import torch.distributed as dist
-        mine = {"timing": info["timing"], "collectives": coll, "frames": hi - lo, "max_memory_allocated_MiB": round(info["max_memory_allocated"])}
+        mine = {"timing": info["timing"], "collectives": coll, "frames": hi - lo, "max_memory_allocated_MiB": round(info["max_memory_allocated"]),
+                "unet_executed_tflop": flops_exec / 1e12}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         per_rank = allr
@@ -516,8 +517,9 @@ def main():
                                       else " (NOT the BASELINE workload: non-default flags)"),
                        "step": "one denoising step of the end-to-end pass; the timed region is the whole pass (VAE encode/decode and both optimiser stages included)",
                        "frames_total": n_total, "passes_timed": passes, "weights": "seeded random SD-1.5 UNet + AutoencoderKL", "codebook_rows": int(K),
-                       "parallelism": (f"frames sharded x{world} (38/37 per rank at 300), yt-plane all-gather + all-reduce per step, decoded frames all-gathered, "
-                                       f"stage 1/2 replicated on every rank (no collective; bit-reproducible); backend {backend}"
+                       "parallelism": (f"frames sharded x{world} ({'/'.join(str(r['frames']) for r in per_rank)} per rank), per step: yt-plane all-gather of x + all-gather of "
+                                       f"every rank's owned noise columns; decoded frames all-gathered slab by slab under the VAE decode (async); stage 1 dealt over the "
+                                       f"ranks (14 KB all-reduce per iteration), stage 2 replicated on every rank (no collective; bit-reproducible); backend {backend}"
                                        + (" -- ranks SHARE GPUs (dry run of the N > 1 path, not a scaling measurement)" if ndev < world else ""))
                                       if world > 1 else "single GPU",
                        "gemm_tile_table_entries_loaded": table_entries},
@@ -529,7 +531,10 @@ def main():
                          "launches": cnt, "avg_launch_ms": ms / max(cnt, 1), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": flops_pass / 1e12,
                          "unet_executed_tflop_per_pass": flops_exec / 1e12,
-                         "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0", "how": prof_how},
+                         "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0", "how": prof_how,
+                         "basis": "event brackets: HIP events on the launch stream around each launch (the interval includes waiting for CUs held by co-running "
+                                  "side-stream kernels); the kernel-time basis (rocprofv3 --kernel-trace of the same command) is profiles/r5_bench_kernel_stats.txt -- "
+                                  "for this kernel the two agree to 1 %"},
         }
         if prof and len(prof) > 2:
             # the other two matrix-pipe consumers of the denoise loop, same profiled pass, same units (the 48 PFLOP of VidToMe score
@@ -542,7 +547,10 @@ def main():
                 pa = pfl / (pms * 1e-3) / 1e12 if pms > 0 else 0.0
                 res[key] = {"bound": "mfma", "kernel": what, "achieved": pa, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": pa / MFMA_F16_DENSE_PEAK_TFLOPS, "calls": pcnt, "kernel_seconds": pms * 1e-3, "algorithmic_tflop_in_calls": pfl / 1e12,
-                            "traffic": None, "how": prof_how}
+                            "traffic": None, "how": prof_how,
+                            "basis": "event brackets around each CALL on its launch stream (tile selection, queueing behind the other stream's kernels and, for the "
+                                     "match, the selection kernels are inside the bracket): lower than the kernel-time basis of profiles/r5_bench_kernel_stats.txt "
+                                     "(round 4: GEMM family 0.37 by brackets, 0.45 by kernel time; match 0.11 / 0.104)"}
         if per_rank:
             ph = sorted(per_rank[0]["timing"])
             names = sorted({k for r in per_rank for k in r["collectives"]})
@@ -555,10 +563,17 @@ def main():
                                     "bytes_per_rank": max(r["collectives"].get(k, {}).get("bytes", 0) for r in per_rank)} for k in names},
                 "seconds_in_collectives_max": round(max(sum(c["seconds"] for c in r["collectives"].values()) for r in per_rank), 4),
                 "collective_bytes_per_denoise_step_per_rank": int(sum(per_rank[0]["collectives"].get(k, {}).get("bytes", 0)
-                                                                      for k in ("all_gather_frames", "all_reduce_yt_noise")) / max(passes * n_steps, 1)),
+                                                                      for k in ("all_gather_frames", "all_gather_yt_noise", "all_reduce_yt_noise")) / max(passes * n_steps, 1)),
                 "max_memory_allocated_MiB": [r["max_memory_allocated_MiB"] for r in per_rank],
-                "note": "seconds in a collective = host clock between device synchronises around the call on that rank: the wait for the slowest rank "
-                        "is inside it (min over ranks ~ the transfer itself, max ~ transfer + load imbalance)"}
+                # the UNet work each rank executed in the timed region (its xy chunks + its share of the yt items): max / mean = the load imbalance
+                # the frame split and the item deal leave, i.e. the best scaling efficiency the denoise phase can reach
+                "unet_executed_tflop": [round(r["unet_executed_tflop"], 1) for r in per_rank],
+                "unet_flop_balance_max_over_mean": round(max(r["unet_executed_tflop"] for r in per_rank) * len(per_rank)
+                                                         / max(sum(r["unet_executed_tflop"] for r in per_rank), 1e-9), 4),
+                "note": "seconds in a collective = HIP events on the issuing stream around the call, resolved after the pass (no device synchronise in "
+                        "the timed region): the wait for the slowest rank to reach the collective is inside the interval (min over ranks ~ the transfer "
+                        "itself, max ~ transfer + load imbalance); all_gather_decoded_async = bytes handed to async all-gathers under the VAE decode, "
+                        "..._wait = what of them was still exposed when the last slab had been decoded"}
         if a.epochs > 0 and info["timing"]["stage2"] > 0:
             # Path 2's dominant kernel group: one stage-2 iteration (gather, losses, codebook gradient, dense Adam).  Algorithmic HBM bytes per
             # iteration: (56 + 48 + 24) b P for the mini-batch + 84 K for the dense Adam stream; time = the stage's wall clock inside

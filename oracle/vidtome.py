@@ -88,8 +88,8 @@ def compute_merge(x, F, bank, randf, coin, local_ratio=0.6, global_ratio=0.5, gl
     """patch.py:14-91 for one patched block.  x: [2F, N, C] (norm1 output), bank: [2, Tb, C] or None.
     randf: the torch.randint draw(s) of merge.py:56-58 -- an int, or one per randframe round for F > target_stride (8 -> 2 -> 1);
     coin: the torch.rand(1) draw of patch.py:61.  Returns dict(merged [2,T,C], unmerge(y)->[2F,N,C], bank_new,
-    gather (source code per merged slot: >=0 row of joined x, <0 ~row of bank), unm (per joined position)); maps are 1-D when the
-    batch shares them (align_batch) and [2, .] otherwise."""
+    gather (source code per merged slot: >=0 row of joined x, <0 ~row of bank), unm (per joined position), bank_src (merged slot per row
+    of bank_new)); maps are 1-D when the batch shares them (align_batch) and [2, .] otherwise."""
     B2, N, C = x.shape
     xj = x.reshape(2, F * N, C)                           # join_frame (vidtome/utils.py:32-35)
     randfs = list(randf) if isinstance(randf, (list, tuple)) else [randf]
@@ -111,7 +111,8 @@ def compute_merge(x, F, bank, randf, coin, local_ratio=0.6, global_ratio=0.5, gl
     def unmerge_with(umap):
         return lambda y: _take(y, umap).reshape(B2, N, -1)
     if not merge_global or bank is None:
-        return dict(merged=local, unm=unm1, gather=mrg1, bank_new=local.clone() if merge_global else None, unmerge=unmerge_with(unm1), rounds=rnd)
+        return dict(merged=local, unm=unm1, gather=mrg1, bank_new=local.clone() if merge_global else None, unmerge=unmerge_with(unm1), rounds=rnd,
+                    bank_src=torch.arange(TL))
     Tb = bank.shape[1]
     if coin > global_rand:                                 # patch.py:61-65 local tokens are src
         tokens = torch.cat([local, bank], 1)
@@ -126,4 +127,5 @@ def compute_merge(x, F, bank, randf, coin, local_ratio=0.6, global_ratio=0.5, gl
     local_rows = _compose(mrg1, (mrg2 - loff).clamp(0, TL - 1))
     gather = torch.where((mrg2 >= loff) & (mrg2 < loff + TL), local_rows, -(mrg2 - boff) - 1)
     bank_new = _take(merged, unm2[..., loff:loff + TL])    # patch.py:80 u(merged_tokens): the local chunk of the unmerge
-    return dict(merged=merged, unm=unm, gather=gather, bank_new=bank_new, unmerge=unmerge_with(unm), rounds=rnd)
+    return dict(merged=merged, unm=unm, gather=gather, bank_new=bank_new, unmerge=unmerge_with(unm), rounds=rnd,
+                bank_src=unm2[..., loff:loff + TL])     # merged slot each row of bank_new was taken from

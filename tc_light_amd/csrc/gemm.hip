@@ -594,8 +594,11 @@ static int heuristic_cfg(int M, int N, int K, int ldc, int ldr, bool has_resid, 
     return (N % 128 == 0 || N > 512) ? 9 : 10;
 }
 
+static int g_near_on = -1;      // un-tabled shapes take their nearest-M twin's tile (TCL_GEMM_NEAR, re-read by tcl_gemm_autotune / tcl_gemm_tune_load)
+static void read_near_env() { const char* e = getenv("TCL_GEMM_NEAR"); g_near_on = !(e && atoi(e) == 0); }
+
 static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
-                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st) {
+                    int lda, int ldw, int ldc, int ldr, int act, const ConvP& cp, hipStream_t st, TclProfScope* ps = nullptr) {
     if (act == 2 && (N % 64 != 0 || (ldc & 7) || resid)) return TCL_EINVAL;      // GEGLU epilogue: 64-column [value | gate] groups
     if (g_tune_cfg) {
         if (!cfg_ok(g_tune_cfg, M, N, K, ldc, ldr, resid != nullptr, act, cp)) return TCL_EINVAL;
@@ -621,9 +624,11 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     // A shape the table does not hold, but whose twin with another row count it does (the same layer in a pass over another number of frames: a
     // group cut at a chunk boundary, the last window of a clip), takes the twin's tile when the row counts are within 2.5x of each other: the best
     // tile moves little with M at these sizes, timing costs a host sync and ~40 launches, and every tile yields the same bits.  The guess lives in
-    // its own cache (tcl_gemm_tune_save writes measured entries only).  TCL_GEMM_NEAR=0: off (the re-tuning tools measure every shape).
-    static const bool near_on = !(getenv("TCL_GEMM_NEAR") && atoi(getenv("TCL_GEMM_NEAR")) == 0);
-    if (near_on) {
+    // its own cache (tcl_gemm_tune_save writes measured entries only: with the timed tuner on, a shape that has such a twin is deliberately NOT measured
+    // -- a pass over a clip whose chunk groups change length every step would otherwise time ~40 shapes per step inside the pass).  TCL_GEMM_NEAR=0: off
+    // (the re-tuning tools measure every shape); the variable is read again whenever tcl_gemm_autotune / tcl_gemm_tune_load is called.
+    if (g_near_on < 0) read_near_env();
+    if (g_near_on) {
         auto nt = g_near_cache.find(key);
         int c = nt != g_near_cache.end() ? nt->second : -1;
         if (c < 0) {
@@ -646,6 +651,7 @@ static int dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, 
     if (g_autotune == 2)      // table-only mode: shapes the loaded table does not know take the static heuristic (no timing, no host sync)
         return run_cfg(fallback, splits, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, cp, st);
     // candidates: LDS-DMA tiles always; the 8-wave kernels when there is no K split and enough tiles to occupy the CUs (tile_ok)
+    if (ps) ps->cancel();         // a tuned call is not a launch: keep its ~40 timed runs and host syncs out of the roofline brackets
     int cand[13], nc = 0;
     static const int all_cfgs[13] = {1, 2, 3, 4, 11, 5, 6, 7, 8, 12, 13, 14, 15};
     for (int c : all_cfgs)
@@ -681,7 +687,7 @@ extern "C" {
 
 int tcl_set_workspace(void* ws, size_t bytes) { g_ws = (float*)ws; g_ws_bytes = ws ? bytes : 0; return TCL_OK; }
 int tcl_gemm_tune(int cfg, int splits) { g_tune_cfg = cfg; g_tune_splits = splits; return TCL_OK; }
-int tcl_gemm_autotune(int enable) { g_autotune = enable; g_near_cache.clear(); if (!enable) g_tune_cache.clear(); return TCL_OK; }
+int tcl_gemm_autotune(int enable) { g_autotune = enable; g_near_cache.clear(); read_near_env(); if (!enable) g_tune_cache.clear(); return TCL_OK; }
 
 // Persistent tuning table: one text line per problem shape, "conv M N K act hasr Hin Win Cin stride Hup cfg".
 int tcl_gemm_tune_save(const char* path) {
@@ -714,6 +720,7 @@ int tcl_gemm_tune_load(const char* path) {
     }
     fclose(f);
     g_near_cache.clear();
+    read_near_env();
     return TCL_OK;
 }
 size_t tcl_gemm_tune_size(void) { return g_tune_cache.size(); }
@@ -724,7 +731,7 @@ int tcl_gemm_f16(const void* A, const void* W, const void* bias, const void* res
     ConvP cp = {};
     TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * N * K);
     return dispatch((const _Float16*)A, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, lda,
-                    ldw, ldc, ldr, act, cp, st);
+                    ldw, ldc, ldr, act, cp, st, &ps);
 }
 
 int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* resid, void* Y, int B, int Hin, int Win, int Cin,
@@ -741,7 +748,7 @@ int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* 
     const int M = B * cp.Hout * cp.Wout;
     TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * Cout * 9.0 * Cin);
     return dispatch((const _Float16*)X, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)Y, M, Cout,
-                    9 * Cin, 0, 9 * Cin, Cout, Cout, act, cp, st);
+                    9 * Cin, 0, 9 * Cin, Cout, Cout, act, cp, st, &ps);
 }
 
 }  // extern "C"

@@ -33,15 +33,25 @@ struct TclProfClass {
 };
 extern TclProfClass g_tcl_prof[TCL_PROF_NCLS];
 
+// (One host thread issues the launches of both streams -- the Python driver -- so the registry needs no lock; a scope must be closed before the next
+// one of its class opens: the deque pairs e0 / e1 by position.)
 struct TclProfScope {
-    TclProfClass* c; hipStream_t st; hipEvent_t e1;
-    TclProfScope(int cls, hipStream_t s, double work) : c(g_tcl_prof[cls].on ? &g_tcl_prof[cls] : nullptr), st(s), e1(nullptr) {
+    TclProfClass* c; hipStream_t st; hipEvent_t e1; double w;
+    TclProfScope(int cls, hipStream_t s, double work) : c(g_tcl_prof[cls].on ? &g_tcl_prof[cls] : nullptr), st(s), e1(nullptr), w(work) {
         if (!c) return;
         if (c->ev.size() > 8192) c->drain(false);
         hipEvent_t e0 = c->get(); e1 = c->get();
         (void)hipEventRecord(e0, st);
         c->ev.push_back(e0);
         c->work += work; c->launches++;
+    }
+    // this call turned out not to be a plain launch (the in-call tile tuner ran: ~40 launches and a host sync inside the bracket): drop it
+    void cancel() {
+        if (!c) return;
+        c->pool.push_back(c->ev.back()); c->ev.pop_back();
+        c->pool.push_back(e1);
+        c->work -= w; c->launches--;
+        c = nullptr;
     }
     ~TclProfScope() { if (c) { (void)hipEventRecord(e1, st); c->ev.push_back(e1); } }
 };

@@ -29,16 +29,20 @@ DEFAULTS = dict(  # configs/tclight_default.yaml (generation / post_opt sections
     final_factor_t=0.01, win_size_t=64, apply_opt=True, epochs_exposure=35, epochs=70, batch_size=16, lambda_dssim=0.2,
     lambda_flow=0.8, lambda_tv=0.05, feature_lr=0.05, exposure_lr_init=0.01, exposure_lr_final=0.001, seed=12345,
     post_opt_mode="replicated",      # multi-GPU only: how stage 1 / stage 2 run once the decoded frames are all-gathered.
-                                     # "replicated" (default): every rank runs the WHOLE optimisation on all frames, no collective at all --
-                                     #   both stages are bound by streams that do not shrink with the mini-batch share (dense Adam over all K
-                                     #   rows, scatters), path 2 is bit-reproducible, so the replicas agree bit for bit and the result is the
-                                     #   one-GPU result.  "global": ONE parameter set with the mini-batch dealt over the ranks, gradients meet in
+                                     # "replicated" (default): every rank runs stage 2 in full on all frames, no collective at all -- it is
+                                     #   bound by streams that do not shrink with the mini-batch share (Adam over the codebook rows, scatters), and
+                                     #   path 2 is bit-reproducible, so the replicas agree bit for bit; stage 1, whose per-iteration work IS
+                                     #   the mini-batch's slots and whose only exchange is the [N,3,4] gradient (14 KB all-reduce), is dealt over
+                                     #   the ranks (round 5).  "replicated_all": stage 1 replicated too -- the one-GPU result, bit for bit.  "global": ONE parameter set with the mini-batch dealt over the ranks, gradients meet in
                                      #   all_reduce / reduce_scatter (2 x 12 K bytes per stage-2 iteration over xGMI: slower than replication
                                      #   from K ~ 1e7 up; kept for memory-bound cases).  "shard": the round-1 approximation, each rank's frame
                                      #   block as a video of its own (tracks cut at the block seams) -- NOT the reference's result.
     shard_post_opt=False,            # legacy spelling of post_opt_mode="shard"
-    max_tokens_per_pass=int(os.environ.get("TCL_MAX_TOKENS_PER_PASS", 16_000_000)))
-    # ^ level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split into consecutive groups.  16 M = the
+    max_tokens_per_pass=None)
+    # ^ None: TCL_MAX_TOKENS_PER_PASS (read when the Generator is built), else min(16 M, 80 % of the device's free memory / 10.5 KB) -- a block-major pass
+    #   peaks at ~10.4 KB of activations per level-0 token (90 GB for the 8.64 M tokens of 300 frames at 1280x720): a 288 GB MI355X gets the 16 M
+    #   below, a smaller part or a GPU shared with other processes a cap that fits.
+    #   level-0 tokens (samples x pixels) one block-major UNet pass may carry; longer chunk lists are split into consecutive groups.  16 M = the
     #   whole xy step of 555 frames at 1280x720 in ONE pass (8.6 M tokens, 90 GB peak at 300 frames): rounds 1-3 used 1.5 M (int32-sized tensors);
     #   one group is 1.4 % faster (177.3 vs 179.8 s denoise, profiles/r4_ab_tokens_per_pass.txt) and, more important, its GEMM shapes do not
     #   depend on the random chunk lengths (groups cut at a cap hold 153-156 frames depending on the draws: every step met un-tabled shapes and
@@ -62,6 +66,15 @@ class Generator:
                       global_rand=c.global_rand, align_batch=bool(c.align_batch))
         self.batch_size = 2
         self.timing = {}
+        if c.max_tokens_per_pass is None:
+            env = os.environ.get("TCL_MAX_TOKENS_PER_PASS")
+            if env:
+                c.max_tokens_per_pass = int(env)
+            else:
+                free = 288 << 30
+                if torch.cuda.is_available() and self.dev.type == "cuda":      # the driver's free bytes + what this process's caching allocator holds unused
+                    free = torch.cuda.mem_get_info(self.dev)[0] + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+                c.max_tokens_per_pass = int(min(16_000_000, max(1_000_000, 0.8 * free / 10_500)))
 
     # ------------------------------------------------------------------ data
     def prepare_data(self, frames, background=None):
@@ -221,12 +234,18 @@ class Generator:
         t1 = ev()
         x = self.ddim_sample(self.init_noise.clone(), conds, conds_t, concat_conds)
         t2 = ev()
-        clean_local = self.vae.decode_latents_batch(x, self.batch_size)
         mode = "shard" if c.shard_post_opt else str(c.post_opt_mode)
-        if mode not in ("replicated", "global", "shard"):
-            raise ValueError(f"post_opt_mode {mode!r}: expected replicated | global | shard")
+        if mode not in ("replicated", "replicated_all", "global", "shard"):
+            raise ValueError(f"post_opt_mode {mode!r}: expected replicated | replicated_all | global | shard")
         shard = d.world > 1 and mode == "shard" and c.apply_opt
         lo, hi = d.range(self.n_total)
+        if d.world > 1 and not shard:
+            # decode slab by slab; every slab goes into an async all-gather while the next one decodes (parallel.gather_frames_pipelined)
+            clean_local = None
+            clean = d.gather_frames_pipelined(lambda a, b: self.vae.decode_latents_batch(x[a:b], self.batch_size), x.shape[0], self.n_total,
+                                              slab=int(os.environ.get("TCL_DECODE_SLAB", "8")))
+        else:
+            clean_local = self.vae.decode_latents_batch(x, self.batch_size)
         if shard:
             # Opt-in approximation: stage 1/2 on this rank's frame block as a video of its own (its first frame has no predecessor, tracks
             # are cut at the block boundary; the global track ids restricted to the block and renumbered densely give the partition
@@ -236,19 +255,20 @@ class Generator:
             hw = clean_local.shape[-2] * clean_local.shape[-1]
             uniq, inv_local = torch.unique(unq_inv[lo * hw:hi * hw], return_inverse=True)
             unq_inv, k = inv_local.to(torch.int32), int(uniq.numel())
-        else:
-            clean = d.gather_frames(clean_local, self.n_total)
+        elif clean_local is not None:
+            clean = clean_local
         t3 = ev()
         losses1 = losses2 = None
         if c.apply_opt:
             N = clean.shape[0]
             pd = d if (mode == "global" and d.world > 1) else None      # global: the ranks split every mini-batch and share one parameter set;
             #                                                           # replicated / shard: every rank optimises on its own (no collective)
+            pd1 = d if (mode in ("global", "replicated") and d.world > 1) else None      # stage 1: dealt over the ranks unless replicated_all / shard
             ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
             rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # global mode: the identical schedule on every rank
             s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)
             _, _, losses1 = post_opt.exposure_align(ds, s1, c.epochs_exposure, c.batch_size, c.exposure_lr_init, c.exposure_lr_final,
-                                                    c.lambda_dssim, c.lambda_flow, dist=pd)
+                                                    c.lambda_dssim, c.lambda_flow, dist=pd1)
             t4 = ev()
             if c.epochs > 0:
                 s2 = post_opt.make_schedule(N, c.batch_size, c.epochs, rng)

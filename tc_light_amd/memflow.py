@@ -1,9 +1,13 @@
-"""MemFlowNet pieces on the device (SURVEY 8(f) rank 2 -- the flow estimator that produces stage-2 inputs).
+"""MemFlowNet inference on the device (SURVEY 8(f) rank 2 -- the flow estimator that produces the stage-2 inputs).
 
-So far: the correlation block.  `CorrBlock` keeps the reference's interface (utils/evaluation/memflow/core/Networks/MemFlowNet/corr.py:74-120:
-`CorrBlock(fmap1, fmap2, num_levels=4, radius=4)(coords) -> [B, L*(2r+1)^2, H, W]`, NCHW f32 in and out) but never builds the all-pairs
-volume: windows are computed on demand from an avg-pooled fmap2 pyramid (`tcl_corr_lookup_f32`, csrc/flow.hip).  The encoders, the
-GMA / SK update block and the memory read are not ported yet.
+`MemFlowEngine` = the reference's MemFlowNet (things_memflownet: BasicEncoder fnet / cnet, GMA-SK2 update block, `InferenceCore` + `MemoryManager`,
+utils/evaluation/memflow/...; inference_core_skflow.py:20-54) on f16 NHWC activations: 1x1 convolutions are `tcl_gemm_f16` calls, 3x3 ones the
+implicit-GEMM kernel, the rest lives in csrc/flow.hip (7x7 stem, InstanceNorm, depthwise 15x15 / 7x7 convolutions fused with residual + GELU, convex
+up-sampling), the memory read runs on the flash kernel (head_dim 128).  `CorrBlock` keeps the reference's interface
+(core/Networks/MemFlowNet/corr.py:74-120: `CorrBlock(fmap1, fmap2, num_levels=4, radius=4)(coords) -> [B, L*(2r+1)^2, H, W]`, NCHW f32 in and out)
+but never builds the all-pairs volume: windows are computed on demand from an avg-pooled fmap2 pyramid (`tcl_corr_lookup_f32`).
+`estimate_flows` reproduces VideoDataParser.load_flow (interleaved future / past pairs on one inference core, per-direction warm start).
+Pinned against the reference modules by tests/golden/memflow_*.npz (tests/test_gpu_memflow.py).
 """
 import ctypes
 

@@ -3,12 +3,15 @@
 The reference is single-GPU; the sharding is this engine's design:
   * frames are split in contiguous blocks; VAE encode/decode and the xy-plane denoise touch only local frames;
   * the yt-plane pass needs every frame of a 64-frame window for each latent column: x is all-gathered once per step
-    (concat_conds once per run), the (window, column-chunk) work items are dealt round-robin to the ranks, each rank writes
-    its columns into a zero full-size noise tensor and ONE all-reduce(SUM) assembles it (every element has one writer);
+    (concat_conds once per run), the (window, column-chunk) work items are dealt round-robin to the ranks, and ONE all-gather of every
+    rank's OWNED (frames x columns) pieces hands each rank the noise of its own frame block (every element has one writer; round 5 -- rounds
+    2-4 all-reduced a zero-filled full-size tensor: 16x the bytes on the wire);
   * stage 1/2 optimise ONE global parameter set (generate.py:472-533: one features_dc [K,3] over all frames): the decoded frames are
-    all-gathered once.  Default ("replicated", generate.py DEFAULTS.post_opt_mode): every rank then runs the whole optimisation itself --
-    no collective; both stages are bound by streams that do not shrink with a rank's share of the mini-batch, and path 2 is bit-reproducible
-    so the replicas agree.  "global" mode: the slots of every mini-batch are dealt to the ranks (`deal_slots`), each rank back-propagates its slots with the
+    all-gathered slab by slab WHILE the VAE decodes the next slab (async collectives, `gather_frames_pipelined`).  Default ("replicated",
+    generate.py DEFAULTS.post_opt_mode): stage 1 deals every mini-batch's slots to the ranks (its only exchange is the 14 KB all-reduce of the
+    [N,3,4] gradient) and stage 2 runs in full on every rank -- no collective; it is bound by streams that do not shrink with a rank's share
+    of the mini-batch, and path 2 is bit-reproducible so the replicas agree ("replicated_all" replicates stage 1 as well: the one-GPU bits).
+    "global" mode: the slots of every mini-batch are dealt to the ranks (`deal_slots`), each rank back-propagates its slots with the
     GLOBAL normalisers, and the gradients meet in a collective before the Adam step (`distributed_adam_loop`): stage 1 all-reduces the
     [N,3,4] exposure gradient (14 KB); stage 2 reduce-scatters the dense [3,K] codebook gradient, every rank owns 1/world of the
     codebook's Adam state (p, m, v: the 84 B/row/iteration stream is cut by world) and the updated rows are all-gathered.  Loss
@@ -25,25 +28,36 @@ from .hostlogic import shard_range
 class Dist:
     def __init__(self, rank=0, world=1, timed=False):
         self.rank, self.world = rank, world
-        # timed=True (bench.py, N > 1): every collective is bracketed by a device synchronise and the host clock, so a scaling run can say
-        # how long the ranks sat in collectives (waiting for the slowest rank included) and how many bytes each one moved.  ~3 per denoising step.
+        # timed=True (bench.py, N > 1): every collective is bracketed by two EVENTS on the stream it is issued from -- resolved by
+        # collect_stats() after the pass, so the timed region has no device-wide synchronise in it and compute / communication overlap as in an
+        # un-instrumented run (rounds 3-4 synchronised the device on both sides of every call: ADVICE r4) -- and its bytes are counted.  The
+        # event interval holds the collective AND the wait for the slowest rank to reach it.
         self.timed = timed
         self.stats = {}
+        self._events = []
 
     def _coll(self, name, nbytes, fn):
-        if not self.timed:
+        if not self.timed or not torch.cuda.is_available():
             return fn()
-        import time
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         out = fn()
-        torch.cuda.synchronize()
-        s = self.stats.setdefault(name, {"calls": 0, "seconds": 0.0, "bytes": 0})
-        s["calls"] += 1; s["seconds"] += time.perf_counter() - t0; s["bytes"] += int(nbytes)
+        e1.record()
+        self._events.append((name, int(nbytes), e0, e1))
         return out
+
+    def collect_stats(self):
+        """Resolve the event pairs recorded so far (synchronises on them) -> {name: {calls, seconds, bytes}}, cumulative since reset_stats()."""
+        for name, nbytes, e0, e1 in self._events:
+            e1.synchronize()
+            s = self.stats.setdefault(name, {"calls": 0, "seconds": 0.0, "bytes": 0})
+            s["calls"] += 1; s["seconds"] += e0.elapsed_time(e1) * 1e-3; s["bytes"] += nbytes
+        self._events = []
+        return self.stats
 
     def reset_stats(self):
         self.stats = {}
+        self._events = []
 
     @classmethod
     def from_env(cls):
@@ -69,15 +83,56 @@ class Dist:
             parts.append(out[r][:hi - lo])
         return torch.cat(parts)
 
+    def gather_frames_pipelined(self, produce, n_local, n_total, slab=8):
+        """gather_frames of frames that are still being produced: produce(a, b) -> this rank's frames [a, b) (e.g. the VAE decode of a slab of
+        latents).  Every slab is handed to an ASYNC all-gather as soon as it exists, so the transfer of slab s rides under the production of slab
+        s + 1 (RCCL runs collectives on its own stream; the only exposed transfer is the last slab's).  Same result as
+        gather_frames(produce(0, n_local), n_total)."""
+        if self.world == 1:
+            return produce(0, n_local)
+        nmax = -(-n_total // self.world)
+        nslab = -(-nmax // slab)
+        works, outs, shape = [], [], None
+        for s_ in range(nslab):
+            a, b = min(s_ * slab, n_local), min((s_ + 1) * slab, n_local)
+            part = produce(a, b) if b > a else None
+            if shape is None:
+                shape, dt, dv = tuple(part.shape[1:]), part.dtype, part.device
+            pad = torch.zeros((slab,) + shape, dtype=dt, device=dv)
+            if part is not None:
+                pad[:b - a] = part
+            out = torch.empty((self.world * slab,) + shape, dtype=dt, device=dv)
+            works.append(dist.all_gather_into_tensor(out, pad, async_op=True))
+            outs.append(out)
+            if self.timed:
+                st = self.stats.setdefault("all_gather_decoded_async", {"calls": 0, "seconds": 0.0, "bytes": 0})
+                st["calls"] += 1; st["bytes"] += out.numel() * out.element_size()
+        self._coll("all_gather_decoded_async_wait", 0, lambda: [w.wait() for w in works])
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_range(n_total, r, self.world)
+            for s_ in range(nslab):
+                cnt = min((s_ + 1) * slab, hi - lo) - s_ * slab
+                if cnt > 0:
+                    parts.append(outs[s_][r * slab:r * slab + cnt])
+        return torch.cat(parts)
+
     def my_items(self, items):
         """Round-robin deal of yt-plane work items (identical list on every rank)."""
         return items[self.rank::self.world]
 
     def reduce_full(self, full):
-        """Sum the per-rank partially filled full-size tensors (disjoint support) in place."""
+        """Sum the per-rank partially filled full-size tensors (disjoint support) in place.  (Rounds 2-4's yt exchange; kept for A/B:
+        TCL_YT_EXCHANGE=allreduce.)"""
         if self.world > 1:
             self._coll("all_reduce_yt_noise", full.numel() * full.element_size(), lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM))
         return full
+
+    def all_gather_flat(self, name, send):
+        """-> [world, len(send)]: every rank's equally long flat buffer."""
+        recv = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        self._coll(name, recv.numel() * recv.element_size(), lambda: dist.all_gather_into_tensor(recv.view(-1), send))
+        return recv
 
     def all_reduce_sum(self, t):
         if self.world > 1:
@@ -117,10 +172,27 @@ class Dist:
         return float(t.item())
 
 
+def yt_pieces(items, rank, world):
+    """The (frame range, columns) pieces of the yt noise that `rank` produces: one per frame window -- the columns of all its items of that
+    window (item = (window start, window length, columns, scale_upto, nkeep) writes frames [start, start + nkeep) x columns, and every
+    (frame, column) of the clip has exactly one writer item: generate.py:265-278)."""
+    pieces = []
+    for it in items[rank::world]:
+        f0, f1 = it[0], it[0] + it[4]
+        if pieces and pieces[-1][:2] == (f0, f1):
+            pieces[-1][2].extend(int(c) for c in it[2])
+        else:
+            pieces.append((f0, f1, [int(c) for c in it[2]]))
+    return pieces
+
+
 def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=None):
     """yt-plane pass.  items: list of (window_start, window_len, column_chunk, scale_upto, nkeep) identical on every rank;
     compute(x_full, cc_full, items, noises_t_full) takes this rank's items of ONE window (same window length, reference order) and
-    writes their columns for the window's frames into noises_t_full.  Returns this rank's frame block of the assembled noises_t."""
+    writes their columns for the window's frames into noises_t_full.  Returns this rank's frame block of the assembled noises_t.
+    Exchange: every rank packs the (frames x columns) pieces it produced into one flat buffer, ONE all-gather moves them, and every rank
+    copies the parts that fall into its own frame block out of it -- 1/world of the clip's noise per rank on the wire."""
+    import os
     if x_full is None:
         x_full = d.gather_frames(x_local, n_total)
     nt_full = torch.zeros_like(x_full)
@@ -131,9 +203,35 @@ def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=N
             group = []
         if it is not None:
             group.append(it)
-    d.reduce_full(nt_full)
     lo, hi = d.range(n_total)
-    return nt_full[lo:hi]
+    if d.world == 1:
+        return nt_full[lo:hi]
+    if os.environ.get("TCL_YT_EXCHANGE", "allgather") == "allreduce":
+        d.reduce_full(nt_full)
+        return nt_full[lo:hi]
+    _, C, h, w = nt_full.shape
+    unit = C * h
+    plists = [yt_pieces(items, r, d.world) for r in range(d.world)]
+    pmax = max(sum((f1 - f0) * len(cols) for f0, f1, cols in pl) for pl in plists) * unit
+    dev = nt_full.device
+    cidx = lambda cols: torch.tensor(cols, dtype=torch.int64, device=dev)
+    send = torch.zeros(pmax, dtype=nt_full.dtype, device=dev)
+    off = 0
+    for f0, f1, cols in plists[d.rank]:
+        blk = nt_full[f0:f1].index_select(3, cidx(cols))           # [frames, C, h, columns]
+        send[off:off + blk.numel()] = blk.reshape(-1)
+        off += blk.numel()
+    recv = d.all_gather_flat("all_gather_yt_noise", send)
+    out = torch.zeros((hi - lo, C, h, w), dtype=nt_full.dtype, device=dev)
+    for r, pl in enumerate(plists):
+        off = 0
+        for f0, f1, cols in pl:
+            n = (f1 - f0) * unit * len(cols)
+            a, b = max(f0, lo), min(f1, hi)
+            if a < b:
+                out[a - lo:b - lo].index_copy_(3, cidx(cols), recv[r, off:off + n].view(f1 - f0, C, h, len(cols))[a - f0:b - f0])
+            off += n
+    return out
 
 
 def deal_slots(row, rank, world):

@@ -101,18 +101,52 @@ class InjectedToMe:
         return all(len(q) == 0 for q in self.q.values())
 
 
+def trace_provenance(tr, ids_x, bank_ids):
+    """Engine trace of one merge (tc_light_amd/vidtome.py `trace`) -> (ids of the token every joined position is RESTORED from, ids of the rows of
+    the bank the merge leaves).  ids_x: one id per row of the joined input; bank_ids: ids of the rows of the bank the merge started from (None:
+    no bank yet).  Slot numbering of the merged sequence is free (the engine keeps unmerged tokens in index order, the reference in score order),
+    provenance is not."""
+    n = len(ids_x)
+    m1 = tr.get("mrg1") if tr.get("mrg1") is not None else tr.get("gather")
+    loc = ids_x[m1.cpu().long()] if m1 is not None else ids_x
+    unm = tr["unm"].cpu().long() if tr["unm"] is not None else torch.arange(n)
+    if "mrg2" not in tr:
+        return loc[unm], loc.clone()
+    TL, Tb = tr["TL"], len(bank_ids)
+    cat = torch.empty(TL + Tb, dtype=torch.int64)
+    cat[tr["loff"]:tr["loff"] + TL] = loc
+    cat[tr["boff"]:tr["boff"] + Tb] = bank_ids
+    return cat[tr["mrg2"].cpu().long()][unm], cat[tr["bmap"].cpu().long()]
+
+
+def oracle_provenance(r, ids_x, bank_ids):
+    """The same for the dict oracle.vidtome.compute_merge returns."""
+    g = r["gather"]
+    merged = torch.where(g >= 0, ids_x[g.clamp(min=0)], bank_ids[(-g - 1).clamp(min=0)] if bank_ids is not None else ids_x[g.clamp(min=0)])
+    return merged[r["unm"]], merged[r["bank_src"]]
+
+
 class ComputedToMe:
+    """The oracle deciding its own matches (f16-emulating score rule), beside the engine's recorded maps.
+    agree: fraction of equal entries of the two unmerge maps as stored -- kept for continuity, but it UNDERSTATES agreement by construction: the
+           engine numbers the unmerged tokens in index order, the oracle (like the reference) in score order, so the ~30 % of the positions that are
+           unmerged src tokens never compare equal even when both sides made identical decisions;
+    agree_src (round 5): fraction of the positions that both sides restore from the SAME source token (provenance carried through the banks)."""
+
     def __init__(self, draws, local_ratio=0.6, global_ratio=0.5, global_rand=0.5, traces=None):
         self.draws, self.banks = deque(draws), {}
         self.lr, self.gr, self.grand = local_ratio, global_ratio, global_rand
         self.q = defaultdict(deque)
         for t in traces or []:
             self.q[t["name"]].append(t)
-        self.agree = []
+        self.agree, self.agree_src = [], []
         self.cur = None
+        self.ids_o, self.ids_h, self.serial = {}, {}, 0
 
     def reset(self):
         self.banks.clear()
+        self.ids_o.clear()
+        self.ids_h.clear()
 
     def next_chunk(self):
         self.cur = self.draws.popleft()
@@ -131,6 +165,11 @@ class ComputedToMe:
                 tr = self.q[p].popleft()
                 hu = tr["unm"] if tr["unm"] is not None else torch.arange(F * N)
                 self.agree.append((r["unm"] == hu).float().mean().item() if r["merged"].shape[1] == tr["T"] else 0.0)
+                self.serial += 1
+                ids_x = (self.serial << 32) + torch.arange(F * N, dtype=torch.int64)
+                so, self.ids_o[p] = oracle_provenance(r, ids_x, self.ids_o.get(p))
+                sh, self.ids_h[p] = trace_provenance(tr, ids_x, self.ids_h.get(p))
+                self.agree_src.append((so == sh).float().mean().item())
             return r["merged"], r["unmerge"]
         return tome
 

@@ -10,7 +10,8 @@ test_multi_axis_bank_carry_over = a small multi-axis run with VidToMe ON: pins t
 
 Tolerances (north_star: 1e-3 rel-L2 on the output).  The engine computes in f16 with f32 accumulation, the oracle in f32; the UNet/VAE
 arithmetic of the oracle is parity-unpinned w.r.t. diffusers (oracle/sd15.py header).  With the engine's merge maps injected into the
-oracle the relit frames out of denoise + decode agree to 1e-3 rel-L2 (measured 9.9e-4, asserted < 1.2e-3).  Stage 1/2 then run 105 Adam
+oracle the relit frames out of denoise + decode agree to 1e-3 rel-L2 (measured 9.85e-4, asserted < 1.0e-3 = north_star's figure, and against the
+f16 noise floor of the path: the oracle itself with f16 op outputs, measured in the test).  Stage 1/2 then run 105 Adam
 iterations whose update is +-lr regardless of the gradient's size: the oracle run twice with inputs differing by 1e-7 ends 1.3e-2 apart
 (measured in the test), so after stage 2 the assertion is "within 1.5x the oracle's own self-distance" plus agreement of every
 iteration's loss.  With the oracle's own matching the discrete decisions differ on near-tied f16 scores: figure printed, bounded loosely.
@@ -82,6 +83,17 @@ def test_config1_end_to_end():
     assert tome_i.exhausted()
     clean_i = E.vae_batches(E.OS.vae_decode, sd_vae, lat_i)
     t_den = time.time() - t0
+    # ... and the f16 NOISE FLOOR of this path (round 5): the same oracle composition with every op's output rounded to f16 -- what the reference's
+    # own torch.float16 pipeline does (oracle/sd15.py `half_outputs`) -- against the f32 oracle, same maps, same draws.  The engine's distance
+    # from the f32 oracle is to be read against THIS figure: it fuses norm + activation and keeps f32 accumulators across fused ops, so it
+    # rounds at fewer points than an op-by-op f16 pipeline.
+    with E.OS.half_outputs(), torch.no_grad():
+        cc16 = E.vae_batches(E.OS.vae_encode, sd_vae, d["frames"])
+        tome_16 = E.InjectedToMe(rec.traces)
+        lat16 = E.oracle_denoise(sd_unet, x0, cc16, conds.float(), conds_t.float(), c, tome_16, rec.zs, c.seed, c.seed + 1)
+        clean16 = E.vae_batches(E.OS.vae_decode, sd_vae, lat16)
+    floor = dict(encode=E.rel(cc16, cc), latents=E.rel(lat16, lat_i), decoded=E.rel(clean16, clean_i))
+    print("[e2e config 1] f16 noise floor (oracle with f16 op outputs vs f32 oracle): " + ", ".join(f"{k_} {v:.2e}" for k_, v in floor.items()))
     _, final_i, l1, l2 = E.oracle_post_opt(clean_i, d["past_flows"], d["masks"], inv, c, n)
     # the same two optimiser stages on the oracle, started from the ENGINE's decoded frames: separates the engine's stage-1/2 arithmetic from
     # the conditioning of the reference's algorithm (Adam's first steps are +-lr whatever the gradient's size: 0.05*16/8 * C0 = 0.028 RGB per
@@ -103,7 +115,8 @@ def test_config1_end_to_end():
     dd = (out.cpu() - final_h).abs()
     print(f"[e2e config 1] final vs oracle-from-same-decoded: median |diff| {dd.median().item():.2e}, fraction > 1e-2: {(dd > 1e-2).float().mean().item():.4f}")
     checks = [r["encode"] < 2e-3, r["latents"] < 5e-3,
-              r["decoded"] < 1.2e-3,                   # north_star's 1e-3 rel-L2 on the relit frames out of the denoise + decode path (measured 9.9e-4)
+              r["decoded"] < 1.0e-3,                   # north_star's 1e-3 rel-L2 on the relit frames out of the denoise + decode path (measured 9.85e-4)
+              r["decoded"] < 1.25 * floor["decoded"], r["latents"] < 1.25 * floor["latents"], r["encode"] < 1.25 * floor["encode"],      # ... and no further from f32 than an op-by-op f16 pipeline is
               # after the two optimiser stages no pointwise 1e-3 exists for anyone: the engine must sit within the oracle's own self-distance
               # (x1.5), from the same decoded frames and over the whole path; the per-iteration LOSSES must agree (checked below, 2e-2 per
               # iteration -- measured 1e-5 at the last one)
@@ -147,10 +160,11 @@ def test_config1_end_to_end():
         rc = dict(latents=E.rel(lat_h, lat_c))
         if nc >= 4:
             rc["decoded"] = E.rel(stages["clean"].cpu(), E.vae_batches(E.OS.vae_decode, sd_vae, lat_c))
-        ag = np.asarray(tome_c.agree)
-        print(f"[e2e config 1, computed maps, {nc} steps] unmerge-map agreement mean {ag.mean():.3f} min {ag.min():.3f} over {len(ag)} merges; rel-L2: "
+        ag, ags = np.asarray(tome_c.agree), np.asarray(tome_c.agree_src)
+        print(f"[e2e config 1, computed maps, {nc} steps] positions restored from the SAME source token: mean {ags.mean():.3f} min {ags.min():.3f} over {len(ags)} "
+              f"merges (raw equality of the stored unmerge maps, whose slot numbering of unmerged tokens differs by design: mean {ag.mean():.3f}); rel-L2: "
               + ", ".join(f"{k_} {v:.2e}" for k_, v in rc.items()))
-        checks.append(rc["latents"] < 2e-2 and ag.mean() > 0.55)
+        checks.append(rc["latents"] < 2e-2 and ag.mean() > 0.55 and ags.mean() > 0.8)
     assert all(checks) and loss_ok, (checks, loss_ok, r)
 
 

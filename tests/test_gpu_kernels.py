@@ -222,6 +222,7 @@ def test_vidtome_maps_vs_oracle(L):
     N, C = 345, 320
     tome = VidToMe("cuda")
     bank = None
+    serial, table, ids_h, ids_o = 0, {}, None, None
     for F, randf, coin in [(4, 2, 0.9), (3, 0, 0.7), (4, 1, 0.1), (1, -1, 0.3)]:
         base = g.standard_normal((1, N, C)).astype(np.float32)
         x = torch.from_numpy(base + 0.3 * g.standard_normal((2 * F, N, C)).astype(np.float32)).half()
@@ -238,6 +239,20 @@ def test_vidtome_maps_vs_oracle(L):
         rest_h, rest_o = mh[:, um], r["merged"][:, r["unm"]]
         agree = (rest_h == rest_o).all(-1).float().mean().item()
         assert agree > 0.995, agree
+        # provenance bookkeeping of the whole-path tests (tests/e2e_oracle.py): ids carried through the engine's recorded maps / the oracle's
+        # dict must name exactly the tokens the restored VALUES come from, banks included
+        import e2e_oracle as E
+        serial += 1
+        ids = (serial << 32) + torch.arange(F * N, dtype=torch.int64)
+        for i_, v_ in zip(ids.tolist(), x.float().reshape(2, F * N, C)[0]):
+            table[i_] = v_
+        sh, ids_h = E.trace_provenance(tome.trace[-1], ids, ids_h)
+        so, ids_o = E.oracle_provenance(r, ids, ids_o)
+        assert torch.equal(rest_h[0], torch.stack([table[i_] for i_ in sh.tolist()]))
+        assert torch.equal(rest_o[0], torch.stack([table[i_] for i_ in so.tolist()]))
+        assert torch.equal(tome.banks["blk"].cpu().float()[0], torch.stack([table[i_] for i_ in ids_h.tolist()]))
+        assert abs((sh == so).float().mean().item() - agree) < 2e-3
+        ids_o = ids_h.clone()                        # (the oracle continues from the HIP bank below)
         if agree == 1.0:
             # the merged SET must match as well
             hv = torch.from_numpy(g.standard_normal(C).astype(np.float32))

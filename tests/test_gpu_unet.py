@@ -1,7 +1,8 @@
 """GPU parity of the UNet engine (HIP, f16) against the fp32 CPU oracle on identical seeded weights and inputs.
 
 Stage (i)  -- VidToMe indices injected from the HIP run into the oracle: pure numeric parity of ~700 chained kernels.
-              Tolerance: rel-L2 <= 3.5e-3 on eps (f16 activations/weights vs f32 oracle; measured 1.6e-3).
+              Tolerance: rel-L2 <= 2.5e-3 on eps AND <= 1.25x the f16 noise floor (the oracle with f16 op outputs vs itself in f32,
+              measured in the test: 1.7e-3; engine 1.6e-3).
 Stage (ii) -- oracle computes its own matching with the f16-emulating rule: report map agreement and rel-L2.
 The oracle's UNet arithmetic itself is parity-UNPINNED w.r.t. diffusers (see oracle/sd15.py header).
 """
@@ -60,7 +61,8 @@ def test_unet_two_chunks(setup):
     tome.trace = None
     assert len(traces) == 20                         # 10 merging blocks (ds 1, 2) x 2 chunks
     # ---- stage (i): inject the HIP maps into the oracle
-    banks = {}
+    banks32, banks16 = {}, {}
+    banks = banks32
     it = iter(traces)
 
     def tome_injected(p, n1):
@@ -83,14 +85,23 @@ def test_unet_two_chunks(setup):
         merged = cat[:, tr["mrg2"].cpu().long()]
         return merged, (lambda y: y[:, unm].reshape(B2, N, C))
     for k in range(2):
+        it = iter(traces[10 * k:])
         ref = OS.unet_forward(sd, torch.cat([xs[k], xs[k]]), t, text, tome_injected)
         r = rel(hip[k], ref)
-        print(f"[unet parity, injected indices] chunk {k}: rel-L2 = {r:.3e}")
-        assert r < 3.5e-3, r                           # measured 1.6e-3 (f16 activations through ~700 kernels vs the f32 oracle); 2x margin
+        # the f16 noise floor: the SAME oracle with every op's output rounded to f16 (the reference's torch.float16 pipeline, oracle/sd15.py
+        # half_outputs) against the f32 oracle, same injected maps; each precision keeps its own banks from chunk 0 to chunk 1
+        banks, it = banks16, iter(traces[10 * k:])
+        with OS.half_outputs():
+            ref16 = OS.unet_forward(sd, torch.cat([xs[k], xs[k]]), t, text, tome_injected)
+        banks = banks32
+        floor = rel(ref16, ref)
+        print(f"[unet parity, injected indices] chunk {k}: engine vs f32 oracle rel-L2 = {r:.3e}; f16 noise floor (oracle f16 outputs vs f32) = {floor:.3e}")
+        assert r < 2.5e-3 and r < 1.25 * floor, (r, floor)       # measured 1.6e-3 engine / 1.7e-3 floor: the engine is AT the floor of f16 arithmetic
         if k == 0:   # banks for chunk 1 in the oracle = unmerged local tokens; with no bank yet that is `local`
             pass
     # ---- stage (ii): oracle's own matching (f16-emulating tie rule), chunk 0 only (no bank dependence)
-    agree = []
+    import e2e_oracle as E
+    agree, agree_src = [], []
 
     def tome_own(p, n1):
         B2, N, C = n1.shape
@@ -99,11 +110,14 @@ def test_unet_two_chunks(setup):
         r = OV.compute_merge(n1, F, None, 1, 0.9, emulate_f16=True)
         tr = next(t0)
         agree.append((r["unm"] == tr["unm"].cpu().long()).float().mean().item())
+        ids = torch.arange(F * N)
+        agree_src.append((E.oracle_provenance(r, ids, None)[0] == E.trace_provenance(tr, ids, None)[0]).float().mean().item())
         return r["merged"], r["unmerge"]
     t0 = iter(traces[:10])
     ref = OS.unet_forward(sd, torch.cat([xs[0], xs[0]]), t, text, tome_own)
     r = rel(hip[0], ref)
-    print(f"[unet parity, computed indices] unmerge-map agreement per block: {['%.3f' % a for a in agree]}; rel-L2 = {r:.3e}")
+    print(f"[unet parity, computed indices] positions restored from the same source token, per block: {['%.3f' % a for a in agree_src]} "
+          f"(raw equality of the stored maps -- unmerged slots are numbered differently by design: {['%.3f' % a for a in agree]}); rel-L2 = {r:.3e}")
     # random-weight activations are close to isotropic noise, so many cosine scores sit within one f16 ulp of each other and
     # the 1e-3-level activation differences flip some matches; the maps still mostly agree and the output stays close.
     assert min(agree) > 0.7 and r < 3e-2           # measured: 82-97 % of the map entries per block, eps rel-L2 1.5e-2; ~2x margin

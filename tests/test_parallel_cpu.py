@@ -61,6 +61,17 @@ def _worker(rank, world, port, n_total, ret):
     assert torch.equal(cc_full, cc)
     nt = sharded_temporal_pass(d, x[lo:hi].clone(), cc_full, n_total, _items(n_total, 10), _compute)
     full = d.gather_frames(nt, n_total)
+    # rounds 2-4's exchange (all-reduce of a zero-filled full-size tensor) gives the same bits as the all-gather of owned pieces
+    os.environ["TCL_YT_EXCHANGE"] = "allreduce"
+    nt_ar = sharded_temporal_pass(d, x[lo:hi].clone(), cc_full, n_total, _items(n_total, 10), _compute)
+    del os.environ["TCL_YT_EXCHANGE"]
+    assert torch.equal(nt, nt_ar)
+    # frames gathered slab by slab while they are produced (async all-gathers) == the one-shot all-gather, uneven shards and short last slabs
+    calls = []
+    for slab in (2, 3, 64):
+        piped = d.gather_frames_pipelined(lambda a, b: (calls.append((a, b)), cc[lo + a:lo + b] * 2.0)[1], hi - lo, n_total, slab=slab)
+        assert torch.equal(piped, cc * 2.0), slab
+    assert all(b > a for a, b in calls)
     if rank == 0:
         ret.put(full.numpy())            # numpy, not torch tensors: fd-shared tensors need the producer alive until the parent unpickles
     assert d.max_float(float(rank), "cpu") == world - 1
@@ -68,11 +79,11 @@ def _worker(rank, world, port, n_total, ret):
 
 
 def test_sharded_temporal_pass_world2():
-    for n_total in (9, 70):          # one window / two overlapping windows, uneven shards
+    for n_total, world in ((9, 2), (70, 2), (70, 3)):          # one window / two overlapping windows, uneven shards; 3 ranks: uneven item deal
         ctx = mp.get_context("spawn")
         ret = ctx.SimpleQueue()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, ret)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, ret)) for r in range(world)]
         for p in procs:
             p.start()
         got = torch.from_numpy(ret.get())

@@ -164,7 +164,9 @@ def test_config1_end_to_end():
         print(f"[e2e config 1, computed maps, {nc} steps] positions restored from the SAME source token: mean {ags.mean():.3f} min {ags.min():.3f} over {len(ags)} "
               f"merges (raw equality of the stored unmerge maps, whose slot numbering of unmerged tokens differs by design: mean {ag.mean():.3f}); rel-L2: "
               + ", ".join(f"{k_} {v:.2e}" for k_, v in rc.items()))
-        checks.append(rc["latents"] < 2e-2 and ag.mean() > 0.55 and ags.mean() > 0.8)
+        # measured (round 5): 0.979 mean / 0.932 min over the 60 merges of 2 steps, on random-weight (near-isotropic) activations -- the raw figure
+        # of rounds 2-4 (0.59) mostly counted the differently NUMBERED unmerged slots, not different decisions
+        checks.append(rc["latents"] < 2e-2 and ags.mean() > 0.95 and ags.min() > 0.9)
     assert all(checks) and loss_ok, (checks, loss_ok, r)
 
 

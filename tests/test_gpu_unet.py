@@ -3,7 +3,8 @@
 Stage (i)  -- VidToMe indices injected from the HIP run into the oracle: pure numeric parity of ~700 chained kernels.
               Tolerance: rel-L2 <= 2.5e-3 on eps AND <= 1.25x the f16 noise floor (the oracle with f16 op outputs vs itself in f32,
               measured in the test: 1.7e-3; engine 1.6e-3).
-Stage (ii) -- oracle computes its own matching with the f16-emulating rule: report map agreement and rel-L2.
+Stage (ii) -- oracle computes its own matching with the f16-emulating rule: fraction of positions restored from the same source token
+              (>= 0.98 per block asserted; measured 0.990-1.000) and rel-L2.
 The oracle's UNet arithmetic itself is parity-UNPINNED w.r.t. diffusers (see oracle/sd15.py header).
 """
 import numpy as np
@@ -120,7 +121,8 @@ def test_unet_two_chunks(setup):
           f"(raw equality of the stored maps -- unmerged slots are numbered differently by design: {['%.3f' % a for a in agree]}); rel-L2 = {r:.3e}")
     # random-weight activations are close to isotropic noise, so many cosine scores sit within one f16 ulp of each other and
     # the 1e-3-level activation differences flip some matches; the maps still mostly agree and the output stays close.
-    assert min(agree) > 0.7 and r < 3e-2           # measured: 82-97 % of the map entries per block, eps rel-L2 1.5e-2; ~2x margin
+    assert min(agree_src) > 0.98 and min(agree) > 0.7 and r < 3e-2      # measured: 99.0-100 % of the positions per block restored from the same source
+    #                                                                      token (raw map equality 80 %), eps rel-L2 1.2e-2
 
 
 def test_forward_many_equals_sequential(setup):

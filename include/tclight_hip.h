@@ -140,6 +140,11 @@ int tcl_conv3x3_f16(const void* X, const void* W, const void* bias, const void* 
 size_t tcl_groupnorm_workspace_bytes(int B, int C);
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st);
+/* The same with a second output: yraw [B,HW,C1+C2] (may be NULL) receives the un-normalised channel concat cat([x1, x2]) -- the operand of the
+ * up-block ResnetBlock2D's conv_shortcut (diffusers ResnetBlock2D.forward: `input_tensor = conv_shortcut(input_tensor)` on the concatenated
+ * input) -- from the pass that reads x1 / x2 anyway, instead of a concat pass of its own (tcl_concat_channels_f16). */
+int tcl_groupnorm_concat_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, void* yraw, int B, int HW,
+                             int groups, float eps, int silu, void* ws, hipStream_t st);
 /* torch.nn.LayerNorm(C) (BasicTransformerBlock.norm1/2/3). */
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st);
 /* The same, plus metric = y / |y| per row with tcl_tome_normalize_f16's f16 arithmetic (norm1 of a VidToMe-patched block, patch.py:161-166 ->

@@ -29,6 +29,13 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #endif
 #define KV_TILE 64
 #define V_STRIDE 72   // halves: 144 B = 9 x 16 B (odd) -> the 16-lane groups of a ds_read_b128 are conflict-free
+// Head_dim 40's V^T tile: DPV rows of V_STRIDE halves.  PV16 reads 48 rows (40 + the ones row + 7 idle); rounds 2-4 stored 64 (9 KiB per tile, 16 DMA
+// pieces per 64-key stage with the 7 KiB K image).  TCL_DPV40 = 48 (round 5): 48 rows, tile padded to 7 KiB so that a stage is exactly 14 pieces --
+// 12.5 % less L2 -> LDS traffic and two DMA instructions less per tile; the PV32 variant needs all 64 rows.
+#ifndef TCL_DPV40
+#define TCL_DPV40 64
+#endif
+__host__ __device__ constexpr int vt_tile_halves(int dpv) { return dpv == 48 ? 3584 : dpv * V_STRIDE; }
 
 // one_col >= 0: that column (a padding column, >= d) is set to 1 in valid rows (the K panel's ones column for the folded shift)
 __device__ __forceinline__ void pack_rows_blk(int blk, int nblk, const _Float16* __restrict__ src, long bstride, int ld, int T, int H, int d, float scale,
@@ -77,7 +84,7 @@ __device__ __forceinline__ void pack_vt_blk(int tile_idx, int bh, const _Float16
         for (int j = 0; j < 8; ++j) tile[r * st + c8 + j] = x[j];
     }
     __syncthreads();
-    _Float16* out = vt + ((long)bh * ntiles + tile_idx) * DPV * V_STRIDE;
+    _Float16* out = vt + ((long)bh * ntiles + tile_idx) * vt_tile_halves(DPV);
     for (int i = threadIdx.x; i < DPV * 64; i += 256) {
         int dd = i / 64, r = i % 64;
         _Float16 val = tile[r * st + dd];
@@ -128,7 +135,7 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
                                             int kv_div, int nqb, int* __restrict__ flags) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
-    constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = DPV * V_STRIDE * 2, SBYTES = KBYTES + VBYTES;
+    constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = vt_tile_halves(DPV) * 2, SBYTES = KBYTES + VBYTES;
     constexpr int NPIECE = (SBYTES + 1023) / 1024, NPW = (NPIECE + 3) / 4, SSTRIDE = NPIECE * 1024;
     constexpr bool LROW = DPV > D;
     constexpr bool FOLD = DP > D && LROW && (D % 16 == 8);        // spare Q/K column D: lanes hl == 1, element 0 of fragment D/16
@@ -153,9 +160,14 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
     const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
     const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;      // tiles / tiles without padded keys
     const char* kbase = (const char*)(Kp + kbh * Tkp * KS);
-    const char* vbase = (const char*)(Vt + kbh * nt * DPV * V_STRIDE);
+    const char* vbase = (const char*)(Vt + kbh * nt * vt_tile_halves(DPV));
     const char* zero = (const char*)g_flash_zero;
 
+#ifdef TCL_FLASH_PRIO_EXP
+    // lab (round 5, tools/ab/ab_attn.sh): static priority for every other block of an XCD's sequence -- MI355X_MICROARCH "static priority for the
+    // younger half", transplanted to two independent 4-wave blocks sharing a CU.  Measured: see DESIGN 4.12 (not in the product build).
+    if ((bid >> 3) & 1) __builtin_amdgcn_s_setprio(TCL_FLASH_PRIO_EXP);
+#endif
     half8 qf[QB][NQK];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -179,7 +191,8 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
             const int pb_ = (wid + 4 * i) * 1024;                                                                             \
             const char* src_ = (pb_ < KBYTES ? kt_ + pb_ : vt_ + (pb_ - KBYTES)) + lane16;                                    \
-            if (SBYTES % 1024 != 0 || NPW * 4 != NPIECE) src_ = pb_ + lane16 < SBYTES ? src_ : zero + lane16;                 \
+            if (SBYTES % 1024 != 0) src_ = pb_ + lane16 < SBYTES ? src_ : zero + lane16;                                      \
+            else if (NSTG != 3 && NPW * 4 != NPIECE && (wid + 4 * i) >= NPIECE) continue;   /* nothing to issue past the stage (wave-uniform; the 3-slot ring COUNTS its pieces: it keeps the dump piece) */ \
             const int dst_ = (wid + 4 * i) < NPIECE ? st_ + pb_ : NSTG * SSTRIDE;      /* pieces past the stage: 1 KiB dump */  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
                                              (__attribute__((address_space(3))) void*)(lds0 + dst_), 16, 0, 0);               \
@@ -838,7 +851,7 @@ static void flash_prof_drain(bool all) {
 template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0, int PVW = 16>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st, int* flags = nullptr, bool count = true) {
-    constexpr int SB = KV_TILE * (DP + 8) * 2 + DPV * V_STRIDE * 2, NPIECE = (SB + 1023) / 1024;
+    constexpr int SB = KV_TILE * (DP + 8) * 2 + vt_tile_halves(DPV) * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
@@ -912,7 +925,7 @@ size_t tcl_attention_kv_bytes(int Bkv, int H, int Tk, int d) {
 // runs it on another stream than the attention itself passes pack_kv bit 2 (and bit 0 = 0) to tcl_attention_f16 afterwards.
 static int attention_pack(const void* q, int ldq, long qbs, const void* k, int ldk, long kbs, const void* v, int ldv, long vbs, int B, int H, int Tq,
                           int Tk, int d, float scale, int kv_div, int pack_q, int pack_kv, void* ws_q, void* ws_kv, hipStream_t st) {
-    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = rup(d, 32), Bkv = B / kv_div;
+    const int Tqp = rup(Tq, 256), Tkp = rup(Tk, 64), DP = rup(d, 16), KS = DP + 8, DPV = d == 40 && !flash_pv32() ? TCL_DPV40 : rup(d, 32), Bkv = B / kv_div;
     _Float16* Qp = (_Float16*)ws_q;
     _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (((size_t)Bkv * H * Tkp * KS + 511) / 512) * 512;        // 1-KiB aligned
@@ -963,9 +976,9 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     // for the 3-slot / 3-block variant).  d = 80: one block, 2-slot ring (50 KB LDS -> 3 blocks per CU)
     const bool qb2 = (long)B * (pair ? 2 : 1) * H * (Tqp / 256) >= 1024;
     static const int var40 = getenv("TCL_FLASH40") ? atoi(getenv("TCL_FLASH40")) : 0;      // tuning hook: force a d = 40 variant (tools/ab)
-    if (d == 40 && var40 == 4) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
-    if (d == 40 && var40 == 2) return launch_flash<40, 48, 64, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 40 && var40 == 3) return launch_flash<40, 48, 64, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40 && var40 == 4 && TCL_DPV40 == 64 && !flash_pv32()) return launch_flash40p(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, ldo, obs, kv_div, st);
+    if (d == 40 && var40 == 2) return launch_flash<40, 48, TCL_DPV40, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40 && var40 == 3) return launch_flash<40, 48, TCL_DPV40, 1, 4, 2, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 40 && flash_pv32()) {
         if (qb2 && var40 == 0) {
             int* flags = (int*)((char*)ws_q + (((size_t)B * H * Tqp * DP * 2 + 255) / 256) * 256);
@@ -980,12 +993,12 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
         // speculative softmax (no row maxima in the loop), then the exact kernel over the blocks that flagged an f16 overflow of P (normally none:
         // its blocks read one flag and leave)
         int* flags = (int*)((char*)ws_q + (((size_t)B * H * Tqp * DP * 2 + 255) / 256) * 256);
-        int rc = launch_flash<40, 48, 64, 2, 4, 2, 0, 1>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags);
-        if (rc == TCL_OK) rc = launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags, false);
+        int rc = launch_flash<40, 48, TCL_DPV40, 2, 4, 2, 0, 1>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags);
+        if (rc == TCL_OK) rc = launch_flash<40, 48, TCL_DPV40, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st, flags, false);
         return rc;
     }
-    if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, 64, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
-                                          : launch_flash<40, 48, 64, 1, 2, 1, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, TCL_DPV40, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
+                                          : launch_flash<40, 48, TCL_DPV40, 1, 2, 1, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_gn_reduce(const float* __restrict__ pa
 __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
                                                   const float* __restrict__ sums, const _Float16* __restrict__ gamma,
                                                   const _Float16* __restrict__ beta, float inv_n, float eps, int G, _Float16* __restrict__ y, int HW,
-                                                  int silu) {
+                                                  int silu, _Float16* __restrict__ yraw) {
     const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8, cpg = C / G;
     const long total = (long)HW * nchunk;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
             o[j] = (_Float16)a;
         }
         *(h8*)(y + ((long)b * HW + row) * C + ch) = o;
+        if (yraw) *(h8*)(yraw + ((long)b * HW + row) * C + ch) = v;      // the un-normalised concat, for the ResNet block's 1x1 shortcut (round 5: was a pass of its own)
     }
 }
 
@@ -396,6 +397,10 @@ static inline int gn_blocks_cap(int B) { (void)B; return 256; }
 size_t tcl_groupnorm_workspace_bytes(int B, int C) { (void)C; return ((size_t)B * gn_blocks_cap(B) + B) * 64 * 2 * 4 + 256; }
 int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, int B, int HW,
                       int groups, float eps, int silu, void* ws, hipStream_t st) {
+    return tcl_groupnorm_concat_f16(x1, C1, x2, C2, gamma, beta, y, nullptr, B, HW, groups, eps, silu, ws, st);
+}
+int tcl_groupnorm_concat_f16(const void* x1, int C1, const void* x2, int C2, const void* gamma, const void* beta, void* y, void* yraw, int B, int HW,
+                             int groups, float eps, int silu, void* ws, hipStream_t st) {
     const int C = C1 + C2;
     TCL_CHECK_ARG(x1 && gamma && beta && y && ws && B > 0 && HW > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C / groups >= 4 && C1 % 8 == 0 && C2 % 8 == 0);
     TCL_CHECK_ARG(C2 == 0 || x2);
@@ -407,7 +412,7 @@ int tcl_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const void
     long chunks = (long)HW * (C / 8);
     hipLaunchKernelGGL(k_gn_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
                        (const _Float16*)x1, C1, (const _Float16*)x2, C2, sums, (const _Float16*)gamma, (const _Float16*)beta,
-                       1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu);
+                       1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu, (_Float16*)yraw);
     TCL_LAUNCH_RET();
 }
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st) {

@@ -171,21 +171,28 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
 // d(loss)/d(codebook): cat row j0 + blockIdx.y.  ATOMIC == false: the ids of one frame are distinct, so a launch over ONE row is a conflict-free
 // read-modify-write and the rows of a mini-batch are launched one after the other (fixed order: deterministic, and no atomic unit in the way);
 // ATOMIC == true (ids that repeat inside a frame): all rows in one launch, float atomics, order not reproducible.
+// cmask != null (lazy schedule, round 5): the clamp test of the gathered value comes from the mask byte the lazy gather wrote (bit c: channel c
+// inside [0, 1]) -- the codebook row in memory may still be steps behind, and the mask saves this kernel's three feat reads per pixel.
 template <bool ATOMIC>
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
                                const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, const int* __restrict__ flow_shift,
-                               int b, int j0, float* __restrict__ gfeat, int P, size_t K) {
+                               int b, int j0, float* __restrict__ gfeat, int P, size_t K, const unsigned char* __restrict__ cmask) {
     const int j = j0 + blockIdx.y, f = fidx[j];
     if (j >= b) pre_scale = __builtin_ldexpf(pre_scale, -flow_shift[fidx[j - b]]);
     const int* iv = inv + (size_t)f * P;
     const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
     const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
+    const unsigned char* cm = cmask ? cmask + (size_t)j * P : nullptr;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         size_t id = (size_t)iv[p];
+        const int mk = cm ? cm[p] : 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = feat[c * K + id] * SH_C0 + 0.5f, gc = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
-            if (v >= 0.f && v <= 1.f && gc != 0.f) {
+            const float gc = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
+            bool inr;
+            if (cm) inr = (mk >> c) & 1;
+            else { const float v = feat[c * K + id] * SH_C0 + 0.5f; inr = v >= 0.f && v <= 1.f; }
+            if (inr && gc != 0.f) {
                 if (ATOMIC) atomicAdd(gfeat + c * K + id, gc * SH_C0);
                 else gfeat[c * K + id] += gc * SH_C0;
             }
@@ -648,6 +655,59 @@ __global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __r
         }
     }
 }
+// ---- round 5: ONE visit per row and iteration with a write.  The catch-up launch is gone: the gather replays a row's skipped steps in REGISTERS
+// (read-only: p, m, v, t_last) and hands the clamp mask on; the step kernel replays them again (the same instruction sequence: same bits) and
+// applies the gradient.  Per row 156 B instead of 208 B of traffic, one launch less per iteration.
+__global__ void k_gather_codebook_lazy(const float* __restrict__ feat, const float* __restrict__ m, const float* __restrict__ v,
+                                       const int* __restrict__ t_last, const int* __restrict__ inv, const int* __restrict__ fidx,
+                                       float* __restrict__ out, unsigned char* __restrict__ cmask, int P, size_t K, int upto, float lr, float b1,
+                                       float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    const int j = blockIdx.y, f = fidx[j];
+    const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P; unsigned char* cm = cmask + (size_t)j * P;
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
+        const size_t id = (size_t)iv[px];
+        const int tl = t_last[id];
+        float pp[3], mm[3], vv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp[c] = feat[c * K + id];
+        if (tl < upto) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
+            adam_replay(pp, mm, vv, tl + 1, upto, lr, b1, b2, eps, bc1, bc2);
+        }
+        int mk = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float val = pp[c] * SH_C0 + 0.5f;
+            mk |= (val >= 0.f && val <= 1.f) ? (1 << c) : 0;
+            o[c * P + px] = fminf(fmaxf(val, 0.f), 1.f);
+        }
+        cm[px] = (unsigned char)mk;
+    }
+}
+// rows of the cat rows blockIdx.y: whatever step they stand at (< step), replay up to step - 1 without gradient, then apply `step` with the
+// (complete) gradient and clear it.  One thread per row wins the atomicMax of the step counter and learns where the row stood.
+__global__ void k_adam_step_rows_lazy(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
+                                      float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
+                                      float b1, float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
+    const float c1 = bc1[step], c2 = bc2[step];
+    for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
+        const size_t id = (size_t)iv[px];
+        if (t_last[id] >= step) continue;
+        const int tl = atomicMax(t_last + id, step);
+        if (tl >= step) continue;                                  // stepped by another frame of this mini-batch
+        float pp[3], mm[3], vv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
+        if (tl < step - 1) adam_replay(pp, mm, vv, tl + 1, step - 1, lr, b1, b2, eps, bc1, bc2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            adam_elem(pp[c], mm[c], vv[c], g[c * K + id], lr, b1, b2, eps, c1, c2);
+            p[c * K + id] = pp[c]; m[c * K + id] = mm[c]; v[c * K + id] = vv[c]; g[c * K + id] = 0.f;
+        }
+    }
+}
 // end of the stage: every row to the last step
 __global__ void k_adam_catchup_all(size_t K, int* __restrict__ t_last, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto,
                                    float lr, float b1, float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
@@ -835,7 +895,7 @@ int tcl_tv_loss(const float* x, int b, int c, int h, int w, float weight, float*
 }
 
 // ---- whole-stage drivers -------------------------------------------------------------------
-struct StageWs { float *cat, *gimg; fxq_t* gpre; fx_t *acc, *efx; int* cidx; MsWs ms; size_t bytes; };
+struct StageWs { float *cat, *gimg; fxq_t* gpre; fx_t *acc, *efx; int* cidx; unsigned char* cmask; MsWs ms; size_t bytes; };
 static StageWs carve_stage(char* base, int b, int h, int w) {
     StageWs S; size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
@@ -843,6 +903,7 @@ static StageWs carve_stage(char* base, int b, int h, int w) {
     S.cat = (float*)take(2 * b * 3 * P * 4); S.gimg = (float*)take(b * 3 * P * 4); S.gpre = (fxq_t*)take(b * 3 * P * sizeof(fxq_t));
     S.acc = (fx_t*)take(ACC_SLOTS * 4 * sizeof(fx_t)); S.efx = (fx_t*)take((size_t)2 * b * 12 * sizeof(fx_t));
     S.cidx = (int*)take(2 * b * 4);
+    S.cmask = (unsigned char*)take(2 * b * P);          // lazy stage 2: clamp mask of the gathered pixels (k_gather_codebook_lazy)
     size_t msb = carve_ms(nullptr, b * 3, h, w).bytes;
     char* mp = take(msb);
     S.ms = carve_ms(mp, b * 3, h, w);
@@ -891,9 +952,19 @@ int tcl_exposure_grad(const float* edited, const float* flows, const float* mask
     TCL_LAUNCH_RET();
 }
 
+struct LazyGather { const float *m, *v, *bc1, *bc2; const int* t_last; int upto; float lr; };      // the lazy schedule's gather (rows may be behind)
+static int unique_tensor_grad_impl(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W, size_t K,
+                                   int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                                   float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, const LazyGather* lz, hipStream_t st);
 int tcl_unique_tensor_grad(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W, size_t K,
                            int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
                            float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, hipStream_t st) {
+    return unique_tensor_grad_impl(target, flows, masks, flow_shift, unq_inv, N, H, W, K, ids_unique, d_cidx, b_loc, b_glob, nvalid_glob, lambda_dssim,
+                                   lambda_flow, lambda_tv, feat, g, loss_part, ws, nullptr, st);
+}
+static int unique_tensor_grad_impl(const float* target, const float* flows, const float* masks, const int* flow_shift, const int* unq_inv, int N, int H, int W, size_t K,
+                                   int ids_unique, const int* d_cidx, int b_loc, int b_glob, int nvalid_glob, float lambda_dssim, float lambda_flow,
+                                   float lambda_tv, const float* feat, float* g, float* loss_part, void* ws, const LazyGather* lz, hipStream_t st) {
     TCL_CHECK_ARG(target && flows && masks && flow_shift && unq_inv && d_cidx && feat && g && loss_part && ws);
     TCL_CHECK_ARG(N > 0 && b_loc > 0 && b_loc <= 64 && b_glob >= b_loc && nvalid_glob >= 0 && H > 160 && W > 160 && K > 0);
     StageWs S = carve_stage((char*)ws, b_loc, H, W);
@@ -901,7 +972,10 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     const int b = b_loc;
     S.cidx = const_cast<int*>(d_cidx);
     if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 4 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
-    hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
+    if (lz) hipLaunchKernelGGL(k_gather_codebook_lazy, pgrid(P, 2 * b), dim3(256), 0, st, feat, lz->m, lz->v, lz->t_last, unq_inv, S.cidx, S.cat, S.cmask, (int)P,
+                               K, lz->upto, lz->lr, 0.9f, 0.999f, 1e-15f, lz->bc1, lz->bc2);
+    else hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
+    const unsigned char* cmask = lz ? S.cmask : nullptr;
     // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
     int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st, b_glob * 3);
     if (rc) return rc;
@@ -914,8 +988,8 @@ int tcl_unique_tensor_grad(const float* target, const float* flows, const float*
     launch_flow_loss(S.cat, S.cidx, flows, masks, b, H, W, fscale, S.gimg, S.gpre, S.acc, pgrid(P, b), flow_shift, st);
     if (ids_unique)          // one cat row per launch, in order: conflict-free read-modify-write of the rows' gradients, no atomics
         for (int j = 0; j < 2 * b; ++j)
-            hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, j, g, (int)P, K);
-    else hipLaunchKernelGGL(k_codebook_bwd<true>, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, 0, g, (int)P, K);
+            hipLaunchKernelGGL(k_codebook_bwd<false>, pgrid(P, 1), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, j, g, (int)P, K, cmask);
+    else hipLaunchKernelGGL(k_codebook_bwd<true>, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.gimg, S.gpre, fscale, flow_shift, b, 0, g, (int)P, K, cmask);
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1), 0, st, S.acc, S.ms.term, 1.f, 0.f, lambda_flow, inv_cnt, ch, cw, loss_part);
     TCL_LAUNCH_RET();
 }
@@ -974,13 +1048,21 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
         const int* cidx = d_cat + (size_t)it * 2 * batch;
-        if (lazy)       // the mini-batch's rows catch up with the steps they skipped (1 .. it) before they are gathered
+        // lazy: the mini-batch's rows are read as they will stand after the steps they skipped (1 .. it): replayed in the gather's registers, and
+        // again -- together with the gradient step it + 1 -- in the step kernel, the only one that writes them (round 5; rounds 3-4 ran a
+        // catch-up launch of their own first: TCL_ADAM_LAZY_V1=1 keeps that schedule for A/B -- same bits)
+        static const bool v1 = getenv("TCL_ADAM_LAZY_V1") && atoi(getenv("TCL_ADAM_LAZY_V1")) != 0;
+        const LazyGather lz = {m, v, bc1, bc2, t_last, it, lr};
+        if (lazy && v1)
             hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,
                                1e-15f, bc1, bc2);
-        int rc = tcl_unique_tensor_grad(target, flows, masks, flow_shift, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
-                                        lambda_flow, lambda_tv, feat, g, losses + it, ws, st);
+        int rc = unique_tensor_grad_impl(target, flows, masks, flow_shift, unq_inv, N, H, W, K, ids_unique, cidx, b, b, nvalid, lambda_dssim,
+                                         lambda_flow, lambda_tv, feat, g, losses + it, ws, (lazy && !v1) ? &lz : nullptr, st);
         if (rc) return rc;
-        if (lazy) {
+        if (lazy && !v1) {
+            hipLaunchKernelGGL(k_adam_step_rows_lazy, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
+                               0.999f, 1e-15f, bc1, bc2);
+        } else if (lazy) {
             const float c1 = (float)(1.0 - pow((double)0.9f, it + 1)), c2 = (float)sqrt(1.0 - pow((double)0.999f, it + 1));
             hipLaunchKernelGGL(k_adam_touched_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
                                0.999f, 1e-15f, c1, c2);

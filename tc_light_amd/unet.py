@@ -95,12 +95,17 @@ class Ops:
                                stride, pad, up[0] if up else 0, up[1] if up else 0, 0, stream())
         return y, Ho, Wo
 
-    def groupnorm(self, x1, c1, gamma, beta, B, HW, eps, silu, x2=None, c2=0, groups=32):
+    def groupnorm(self, x1, c1, gamma, beta, B, HW, eps, silu, x2=None, c2=0, groups=32, raw=False):
+        """raw=True: also return the un-normalised concat [x1 | x2] (written by the same pass) -> (y, yraw)."""
         key = (B, c1 + c2)
         ws = self._gn_ws.get(key)
         if ws is None:
             ws = self._gn_ws[key] = torch.zeros(self.L.tcl_groupnorm_workspace_bytes(B, c1 + c2), dtype=torch.uint8, device=self.dev)   # zeroed once
         y = self.empty(B * HW, c1 + c2)
+        if raw:
+            yr = self.empty(B * HW, c1 + c2)
+            self.L.tcl_groupnorm_concat_f16(x1, c1, x2 if x2 is not None else 0, c2, gamma, beta, y, yr, B, HW, groups, eps, int(silu), ws, stream())
+            return y, yr
         self.L.tcl_groupnorm_f16(x1, c1, x2 if x2 is not None else 0, c2, gamma, beta, y, B, HW, groups, eps, int(silu), ws, stream())
         return y
 
@@ -233,11 +238,16 @@ class UNetEngine:
         o, r = self.ops, self.res[p]
         HW = Hh * Ww
         cx = r["cin"] - cskip
-        hn = o.groupnorm(x, cx, *r["n1"], B, HW, 1e-5, True, x2=skip, c2=cskip)
+        fuse_cat = skip is not None and "sc" in r and os.environ.get("TCL_GN_CONCAT", "1") != "0"
+        hn = o.groupnorm(x, cx, *r["n1"], B, HW, 1e-5, True, x2=skip, c2=cskip, raw=fuse_cat)
+        if fuse_cat:            # norm1's apply pass reads x and skip anyway: it writes the raw concat for the 1x1 shortcut as well (same bits as a concat pass)
+            hn, xc = hn
         h1, _, _ = o.conv3x3(hn, B, Hh, Ww, r["cin"], r["c1"], tproj[p])
         hn2 = o.groupnorm(h1, r["cout"], *r["n2"], B, HW, 1e-5, True)
         if "sc" in r:
-            if skip is not None:
+            if fuse_cat:
+                pass
+            elif skip is not None:
                 xc = o.empty(B * HW, r["cin"])
                 self.L.tcl_concat_channels_f16(x, cx, skip, cskip, xc, B * HW, stream())
             else:

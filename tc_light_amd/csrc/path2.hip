@@ -158,14 +158,22 @@ __global__ void k_expo_fin(const fx_t* __restrict__ efx, const int* __restrict__
     for (int j = 0; j < rows; ++j) gexpo[(size_t)idx[j] * 12 + i] += fx_get(efx[(size_t)j * 12 + i], 1.f / FX_EXPO);
 }
 // out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
+// cmask (may be null): bit c of byte [j][p] = channel c of that pixel lies inside [0, 1] -- the clamp's gradient mask, handed to k_codebook_bwd so that it
+// need not gather the codebook row a second time (round 5: a third of that kernel's traffic).
 __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
-                                  float* __restrict__ out, int P, size_t K) {
+                                  float* __restrict__ out, int P, size_t K, unsigned char* __restrict__ cmask) {
     const int j = blockIdx.y, f = fidx ? fidx[j] : j;
     const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[p];
+        int mk = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c * P + p] = fminf(fmaxf(feat[c * K + id] * SH_C0 + 0.5f, 0.f), 1.f);
+        for (int c = 0; c < 3; ++c) {
+            const float val = feat[c * K + id] * SH_C0 + 0.5f;
+            mk |= (val >= 0.f && val <= 1.f) ? (1 << c) : 0;
+            o[c * P + p] = fminf(fmaxf(val, 0.f), 1.f);
+        }
+        if (cmask) cmask[(size_t)j * P + p] = (unsigned char)mk;
     }
 }
 // d(loss)/d(codebook): cat row j0 + blockIdx.y.  ATOMIC == false: the ids of one frame are distinct, so a launch over ONE row is a conflict-free
@@ -778,7 +786,7 @@ int tcl_apply_exposure(const float* src, const int* idx, const float* expo, floa
 }
 int tcl_gather_codebook(const float* feat, const int* inv, const int* fidx, float* out, int nb, int h, int w, size_t K, hipStream_t st) {
     TCL_CHECK_ARG(feat && inv && out && nb > 0);
-    hipLaunchKernelGGL(k_gather_codebook, pgrid(h * w, nb), dim3(256), 0, st, feat, inv, fidx, out, h * w, K);
+    hipLaunchKernelGGL(k_gather_codebook, pgrid(h * w, nb), dim3(256), 0, st, feat, inv, fidx, out, h * w, K, (unsigned char*)nullptr);
     TCL_LAUNCH_RET();
 }
 int tcl_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
@@ -974,8 +982,8 @@ static int unique_tensor_grad_impl(const float* target, const float* flows, cons
     if (hipMemsetAsync(S.acc, 0, ACC_SLOTS * 4 * sizeof(fx_t), st) != hipSuccess) return TCL_ELAUNCH;
     if (lz) hipLaunchKernelGGL(k_gather_codebook_lazy, pgrid(P, 2 * b), dim3(256), 0, st, feat, lz->m, lz->v, lz->t_last, unq_inv, S.cidx, S.cat, S.cmask, (int)P,
                                K, lz->upto, lz->lr, 0.9f, 0.999f, 1e-15f, lz->bc1, lz->bc2);
-    else hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K);
-    const unsigned char* cmask = lz ? S.cmask : nullptr;
+    else hipLaunchKernelGGL(k_gather_codebook, pgrid(P, 2 * b), dim3(256), 0, st, feat, unq_inv, S.cidx, S.cat, (int)P, K, S.cmask);
+    const unsigned char* cmask = S.cmask;
     // loss = (1-lf)*ld*(1-msssim) + lf*flow + tv  -> fold (1-lf) into the ms-ssim lambda
     int rc = msssim_chain(S.cat, target, S.cidx, b * 3, H, W, (1.f - lambda_flow) * lambda_dssim, S.ms, true, st, b_glob * 3);
     if (rc) return rc;
@@ -1072,7 +1080,7 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         }
     }
     if (lazy) hipLaunchKernelGGL(k_adam_catchup_all, dim3(stream_grid((long)K, 256, 1)), dim3(256), 0, st, K, t_last, feat, m, v, iters, lr, 0.9f, 0.999f, 1e-15f, bc1, bc2);
-    if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P, K);
+    if (images_out) hipLaunchKernelGGL(k_gather_codebook, pgrid(P, N), dim3(256), 0, st, feat, unq_inv, (const int*)nullptr, images_out, (int)P, K, (unsigned char*)nullptr);
     TCL_LAUNCH_RET();
 }
 

@@ -24,6 +24,9 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef TCL_FLASH80_DEFAULT
+#define TCL_FLASH80_DEFAULT 4
+#endif
 #ifndef TCL_FLASH_PV32_DEFAULT
 #define TCL_FLASH_PV32_DEFAULT 0
 #endif
@@ -129,14 +132,15 @@ __device__ __forceinline__ float xhalf_max(float v) {
 
 // (the body of k_flash for ONE block index: the kernel below calls it once, or -- the flag-gated exact pass behind the speculative kernel -- once per
 // flagged index of its stride class)
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW, int NW>
 __device__ __forceinline__ void flash_block(const int bid, const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                             _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                             int kv_div, int nqb, int* __restrict__ flags) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = vt_tile_halves(DPV) * 2, SBYTES = KBYTES + VBYTES;
-    constexpr int NPIECE = (SBYTES + 1023) / 1024, NPW = (NPIECE + 3) / 4, SSTRIDE = NPIECE * 1024;
+    // NW waves per block (4; 8 for head_dim 80, round 5): a K / V^T stage serves 32 QB NW queries -- its DMA pieces per query halve with 8 waves
+    constexpr int NPIECE = (SBYTES + 1023) / 1024, NPW = (NPIECE + NW - 1) / NW, SSTRIDE = NPIECE * 1024;
     constexpr bool LROW = DPV > D;
     constexpr bool FOLD = DP > D && LROW && (D % 16 == 8);        // spare Q/K column D: lanes hl == 1, element 0 of fragment D/16
     constexpr bool PVQ = QB > 1;                                  // PV per query block right behind its softmax (V^T fragments held in registers)
@@ -156,7 +160,7 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
 
     const int head = bid % H, qb_ = (bid / H) % nqb, b = bid / (H * nqb);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hl = lane >> 5, ql = lane & 31;
-    const int q0 = qb_ * (128 * QB) + wid * (32 * QB);
+    const int q0 = qb_ * (32 * NW * QB) + wid * (32 * QB);
     const long bh = (long)b * H + head, kbh = (long)(b / kv_div) * H + head;
     const int nt = Tkp / KV_TILE, nfull = Tk / KV_TILE;      // tiles / tiles without padded keys
     const char* kbase = (const char*)(Kp + kbh * Tkp * KS);
@@ -189,11 +193,11 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
         const char* vt_ = vbase + (long)(IT) * VBYTES;                                                                        \
         const int st_ = ((IT) % NSTG) * SSTRIDE;                                                                              \
         _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                                    \
-            const int pb_ = (wid + 4 * i) * 1024;                                                                             \
+            const int pb_ = (wid + NW * i) * 1024;                                                                            \
             const char* src_ = (pb_ < KBYTES ? kt_ + pb_ : vt_ + (pb_ - KBYTES)) + lane16;                                    \
             if (SBYTES % 1024 != 0) src_ = pb_ + lane16 < SBYTES ? src_ : zero + lane16;                                      \
-            else if (NSTG != 3 && NPW * 4 != NPIECE && (wid + 4 * i) >= NPIECE) continue;   /* nothing to issue past the stage (wave-uniform; the 3-slot ring COUNTS its pieces: it keeps the dump piece) */ \
-            const int dst_ = (wid + 4 * i) < NPIECE ? st_ + pb_ : NSTG * SSTRIDE;      /* pieces past the stage: 1 KiB dump */  \
+            else if (NSTG != 3 && NPW * NW != NPIECE && (wid + NW * i) >= NPIECE) continue;   /* nothing to issue past the stage (wave-uniform; the 3-slot ring COUNTS its pieces: it keeps the dump piece) */ \
+            const int dst_ = (wid + NW * i) < NPIECE ? st_ + pb_ : NSTG * SSTRIDE;      /* pieces past the stage: 1 KiB dump */  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                             \
                                              (__attribute__((address_space(3))) void*)(lds0 + dst_), 16, 0, 0);               \
         }                                                                                                                     \
@@ -601,8 +605,8 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW>
-__global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW, int NW>
+__global__ __launch_bounds__(64 * NW, (MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) * (NW / 4)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb, int* __restrict__ flags, int nblk) {
     if constexpr (D == 40 && QB == 2 && !SPEC) {
@@ -612,13 +616,13 @@ __global__ __launch_bounds__(256, MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1
         if (flags) {
             for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
                 if (!flags[bid]) continue;
-                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
                 __syncthreads();                  // the next item re-uses the LDS ring
             }
             return;
         }
     }
-    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -848,14 +852,14 @@ static void flash_prof_drain(bool all) {
     }
 }
 
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0, int PVW = 16>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB = 1, int MINB = 0, int SPEC = 0, int PVW = 16, int NW = 4>
 static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                         int d, int ldo, long obs, int kv_div, hipStream_t st, int* flags = nullptr, bool count = true) {
     constexpr int SB = KV_TILE * (DP + 8) * 2 + vt_tile_halves(DPV) * 2, NPIECE = (SB + 1023) / 1024;
     const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    const int nqb = Tqp / (128 * QB);
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / (32 * NW * QB);
     const bool prof = g_prof.on && (g_prof.dfilter == 0 || g_prof.dfilter == d);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) {
@@ -864,7 +868,7 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     }
     const int nblk = B * H * nqb;
     const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > 512) ? 512 : nblk;      // gated exact pass: one resident round of blocks walks the flags
-    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW>), dim3(grid), dim3(256), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
+    hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>), dim3(grid), dim3(64 * NW), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
@@ -999,6 +1003,11 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     }
     if (d == 40) return qb2 && var40 != 1 ? launch_flash<40, 48, TCL_DPV40, 2, 4, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st)
                                           : launch_flash<40, 48, TCL_DPV40, 1, 2, 1, 4>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    // d = 80: the 4-wave kernel moves 24.5 KiB of K / V^T image per 128 queries and tile through LDS-DMA -- ~40 B / clk / CU at three blocks per CU, the
+    // measured ceiling of that path (profiles/r3_lds_dma_rate.txt); 8 waves per block (TCL_FLASH80=8) halve the bytes per query.
+    static const int var80 = getenv("TCL_FLASH80") ? atoi(getenv("TCL_FLASH80")) : TCL_FLASH80_DEFAULT;
+    if (d == 80 && var80 == 8 && (long)B * H * (Tqp / 256) >= 256)
+        return launch_flash<80, 80, 96, 1, 2, 1, 1, 0, 16, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);

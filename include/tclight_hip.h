@@ -155,6 +155,13 @@ int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
  * to the two-kernel route, 1e-3 rel-L2 like any two f16 LayerNorms).  N >= 128, N % 32 == 0 (GEGLU: % 64), 16-B aligned rows. */
 int tcl_ln_gemm_f16(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias, const void* resid, void* C,
                     int M, int N, int K, int ldx, int ldw, int ldc, int ldr, int act, hipStream_t st);
+/* The attn2 `to_q` projection of a C = 320 transformer block written straight into the attention kernel's query panel (diffusers Attention.to_q ->
+ * AttnProcessor2_0, utils/model_utils.py:66-67): LayerNorm(x) @ W^T -> ws_q's Qp [B, H, ceil256(Tq), 48], pre-scaled by scale * log2 e, exactly as
+ * tcl_attention_pack_f16 would have packed the Linear's output (same rounding points), without the [M, H d] round trip.  M = B * Tq rows, d = 40.
+ * Rows Tq .. ceil256(Tq) of every (b, h) panel are NOT written: the caller keeps ws_q (tcl_attention_q_bytes) zero-initialised and reuses it.
+ * Follow with tcl_attention_f16(..., pack_kv = 4 (pre-packed), ws_q, ws_kv). */
+int tcl_ln_gemm_qpanel_f16(const void* x, const void* gamma, const void* beta, float eps, const void* W, int M, int H, int d, int Tq, int ldx, int ldw,
+                           float scale, void* ws_q, hipStream_t st);
 int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st);
 /* diffusers GEGLU: in [rows, 2D] -> out [rows, D] = in[:, :D] * gelu(in[:, D:]) (exact erf gelu). */
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st);

@@ -35,6 +35,11 @@ __device__ __forceinline__ void ls_exchange(const _Float16 (&o)[16], uint4v& p0,
     p1 = uint4v{s2[0], s3[0], s2[1], s3[1]};
 }
 
+// Q-panel epilogue (round 5): instead of C [M, N] the result goes straight into the flash kernel's query panel Qp [B, H, Tqp, 48] (csrc/attn.hip:
+// head-major rows of DP = 48 halves, pre-scaled by softmax_scale * log2 e, columns 40..47 zero) -- the attn2 to_q projection of the C = 320
+// transformer blocks then needs neither its [M, 320] output nor the pack pass that re-read it (k_pack_rows: 1.07 s per 300-frame pass).  Rows
+// t >= Tq of the panel are never written here: the caller keeps them zero.  Same rounding points as Linear -> pack: f16(acc), then f16(. * scale).
+struct QPanel { _Float16* panel; int Tq, Tqp; float scale; };
 #ifndef LS_ABL
 #define LS_ABL 0        // lab-only knock-outs (tools/micro/lin_lab.hip): 1 no C stores, 2 no A loads, 4 no residual loads, 8 no sweep (DMA + MFMA)
 #endif
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _F
                                                                        const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                                        _Float16* __restrict__ C, int M, int N, int lda, int ldw, int ldc, int ldr,
                                                                        int act, int tiles_n, int nsplit, const _Float16* __restrict__ gamma,
-                                                                       const _Float16* __restrict__ beta, float eps) {
+                                                                       const _Float16* __restrict__ beta, float eps, QPanel qp) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NST = K / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _F
     const int voff0 = rr * (ldw * 2) + ((ch ^ (rr >> 1)) << 4), voff1 = rr * (ldw * 2) + ((ch ^ (4 + (rr >> 1))) << 4);
     const int m = strip * SW + wid * 32 + col;                                   // this lane's activation row = output row
     const bool live = m < M;
+    const int q_b = qp.panel ? m / qp.Tq : 0, q_t = qp.panel ? m - q_b * qp.Tq : 0, q_H = N / 40;      // panel mode: (sample, token) of the row
     half8 bfr[K / 16];                                                            // B operand: row m, k = 16 ks + 8 hl .. + 7
     {
         const _Float16* ap = A + (long)(live ? m : 0) * lda + 8 * hl;
@@ -192,6 +198,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _F
                 }
                 uint4v p0, p1;
                 ls_exchange(o, p0, p1);
+                if (live && qp.panel) {
+                    half8 v[2] = {__builtin_bit_cast(half8, p0), __builtin_bit_cast(half8, p1)};
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[pc][j] = (_Float16)((float)v[pc][j] * qp.scale);
+                        const int c = n0 + a * 32 + 8 * hl + 16 * pc, head = c / 40, dd = c - head * 40;
+                        _Float16* dst = qp.panel + (((long)q_b * q_H + head) * qp.Tqp + q_t) * 48 + dd;
+                        *(half8*)dst = v[pc];
+                        if (dd == 32) { half8 z; for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f; *(half8*)(dst + 8) = z; }      // the panel's padding columns 40..47
+                    }
+                    continue;
+                }
                 if (live) {
                     const long off = n0 + a * 32 + 8 * hl;
                     if (has_r) {
@@ -216,6 +235,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lin_strip(const _F
 #endif
 }
 
+
+int lin_strip_dispatch_q(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
+                         int lda, int ldw, int ldc, int ldr, int act, hipStream_t st, const _Float16* gamma, const _Float16* beta, float eps, QPanel qp);
 // cfg 12 of csrc/gemm.hip.  Valid for dense A, K == 320, N >= 128 and N % 32 == 0 (GEGLU: N % 64 == 0), 16-B aligned rows.
 bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool has_resid, int act, const ConvP& cp) {
     return !cp.conv && K == 320 && N >= 128 && N % (act == 2 ? 64 : 32) == 0 && N <= 8192 && (lda & 7) == 0 && (ldw & 7) == 0 && (ldc & 7) == 0 &&
@@ -224,6 +246,10 @@ bool lin_strip_ok(int M, int N, int K, int lda, int ldw, int ldc, int ldr, bool 
 
 int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int act, hipStream_t st, const _Float16* gamma, const _Float16* beta, float eps) {
+    return lin_strip_dispatch_q(A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr, act, st, gamma, beta, eps, QPanel{nullptr, 1, 1, 1.f});
+}
+int lin_strip_dispatch_q(const _Float16* A, const _Float16* W, const _Float16* bias, const _Float16* resid, _Float16* C, int M, int N, int K,
+                         int lda, int ldw, int ldc, int ldr, int act, hipStream_t st, const _Float16* gamma, const _Float16* beta, float eps, QPanel qp) {
     if (K != 320) return TCL_EINVAL;
     constexpr int NW = 4;
     const int tn = cdiv(N, 128), strips = cdiv(M, 32 * NW);
@@ -239,8 +265,8 @@ int lin_strip_dispatch(const _Float16* A, const _Float16* W, const _Float16* bia
         (void)hipFuncSetAttribute((const void*)k_lin_strip<320, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128 + 64 * 128 * 2);
         set = true;
     }
-    if (gamma) hipLaunchKernelGGL((k_lin_strip<320, NW, true>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps);
-    else hipLaunchKernelGGL((k_lin_strip<320, NW, false>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps);
+    if (gamma) hipLaunchKernelGGL((k_lin_strip<320, NW, true>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps, qp);
+    else hipLaunchKernelGGL((k_lin_strip<320, NW, false>), dim3(strips * nsplit), dim3(64 * NW), lds, st, A, W, bias, resid, C, M, N, lda, ldw, ldc, ldr, act, tn, nsplit, gamma, beta, eps, qp);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
@@ -255,5 +281,16 @@ int tcl_ln_gemm_f16(const void* x, const void* gamma, const void* beta, float ep
     TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * N * K);
     return lin_strip_dispatch((const _Float16*)x, (const _Float16*)W, (const _Float16*)bias, (const _Float16*)resid, (_Float16*)C, M, N, K, ldx, ldw, ldc,
                               ldr, act, st, (const _Float16*)gamma, (const _Float16*)beta, eps);
+}
+int tcl_ln_gemm_qpanel_f16(const void* x, const void* gamma, const void* beta, float eps, const void* W, int M, int H, int d, int Tq, int ldx, int ldw,
+                           float scale, void* ws_q, hipStream_t st) {
+    TCL_CHECK_ARG(x && gamma && beta && W && ws_q && M > 0 && H > 0 && d == 40 && Tq > 0 && M % Tq == 0);
+    const int N = H * d, K = N;
+    ConvP cp = {};
+    TCL_CHECK_ARG(lin_strip_ok(M, N, K, ldx, ldw, N, N, false, 0, cp) && ldx >= K && ldw >= K);
+    TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * M * N * K);
+    const QPanel qp = {(_Float16*)ws_q, Tq, (Tq + 255) / 256 * 256, scale * 1.4426950408889634f};
+    return lin_strip_dispatch_q((const _Float16*)x, (const _Float16*)W, nullptr, nullptr, (_Float16*)ws_q, M, N, K, ldx, ldw, N, N, 0, st,
+                                (const _Float16*)gamma, (const _Float16*)beta, eps, qp);
 }
 }

@@ -278,6 +278,17 @@ class UNetEngine:
             hit = blk["text_kv"][key] = dict(kv=kv, ws=ws, packed=False, L=Lt, text=text)
         return hit
 
+    def _q_panel(self, B, Hh, Tq, d):
+        """A zero-initialised query-panel workspace per shape, reused by every block (stream order serialises them): tcl_ln_gemm_qpanel_f16 writes the
+        rows t < Tq of every (sample, head) panel and never touches the padding rows, which therefore stay zero."""
+        key = (B, Hh, Tq, d)
+        cache = self.__dict__.setdefault("_qpanels", {})
+        if key not in cache:
+            if len(cache) > 4:
+                cache.clear()
+            cache[key] = torch.zeros(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
+        return cache[key]
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             prio = os.environ.get("TCL_SIDE_PRIO", "")
@@ -390,11 +401,17 @@ class UNetEngine:
         F = Ftot
         # ---- attn2: text cross-attention on the full tokens
         fuse_ln = C == 320 and os.environ.get("TCL_LN_GEMM", "1") != "0"      # norm2 / norm3 ride in the consumer's operand load (strip-resident Linear)
-        q = o.ln_gemm(h, *blk["ln"][1], blk["q2"]) if fuse_ln else o.gemm(o.layernorm(h, *blk["ln"][1], M, C), blk["q2"])
         tk = self._text_kv(blk, text)
         Lt = tk["L"]
-        a = o.attention(q, C, N * C, tk["kv"], 2 * C, Lt * 2 * C, tk["kv"][:, C:], 2 * C, Lt * 2 * C, B, Hd, N, Lt, d,
-                        kv_div=F, ws_kv=tk["ws"], pack_kv=0 if tk["packed"] else 1)
+        if fuse_ln and tk["packed"] and os.environ.get("TCL_QPANEL", "1") != "0":
+            # norm2 -> to_q straight into the attention kernel's query panel (linstrip.hip Q-panel epilogue): no [M, C] output, no pack pass
+            wq = self._q_panel(B, Hd, N, d)
+            L.tcl_ln_gemm_qpanel_f16(h, *blk["ln"][1], 1e-5, blk["q2"], M, Hd, d, N, C, C, d ** -0.5, wq, stream())
+            a = o.attention(wq, C, N * C, None, 0, 0, None, 0, 0, B, Hd, N, Lt, d, kv_div=F, packed=(wq, tk["ws"]))
+        else:
+            q = o.ln_gemm(h, *blk["ln"][1], blk["q2"]) if fuse_ln else o.gemm(o.layernorm(h, *blk["ln"][1], M, C), blk["q2"])
+            a = o.attention(q, C, N * C, tk["kv"], 2 * C, Lt * 2 * C, tk["kv"][:, C:], 2 * C, Lt * 2 * C, B, Hd, N, Lt, d,
+                            kv_div=F, ws_kv=tk["ws"], pack_kv=0 if tk["packed"] else 1)
         tk["packed"] = True
         h = o.gemm(a, blk["o2"][0], blk["o2"][1], resid=h)
         self._fl(2.0 * M * C * C * 2 + 4.0 * M * Lt * C)

@@ -500,6 +500,42 @@ def test_ln_gemm_fused(L):
         assert (one != two).float().mean().item() < 0.02          # same rounding points: only rows whose statistics differ in the last bit move
 
 
+def test_ln_gemm_qpanel_equals_linear_then_pack(L):
+    """Round 5: the attn2 to_q projection written straight into the flash kernel's query panel (tcl_ln_gemm_qpanel_f16) must leave the SAME BITS in the
+    panel as tcl_ln_gemm_f16 followed by the pack pass of tcl_attention_pack_f16 -- and never touch the panel's padding rows; the attention that
+    follows (pre-packed Q, text K / V packed earlier) then equals the unfused call bit for bit.  Tq = 345 (panel rows padded to 512), 3 samples,
+    the last strip of 128 rows partly past M."""
+    g = torch.Generator(device="cuda").manual_seed(33)
+    B, Hh, d, Tq, Lt = 3, 8, 40, 345, 154
+    C, M = Hh * d, 3 * 345
+    x = (torch.randn(M, C, device="cuda", generator=g) * 1.5 + 0.2).to(H)
+    ga, be = (1 + 0.2 * torch.randn(C, device="cuda", generator=g)).to(H), (0.1 * torch.randn(C, device="cuda", generator=g)).to(H)
+    W = (torch.randn(C, C, device="cuda", generator=g) / C ** 0.5).to(H)
+    kv = torch.randn(B, Lt, 2 * C, device="cuda", generator=g).to(H)
+    nq, nkv = L.tcl_attention_q_bytes(B, Hh, Tq, d), L.tcl_attention_kv_bytes(B, Hh, Lt, d)
+    # the two-step route
+    q = torch.empty(M, C, device="cuda", dtype=H)
+    L.tcl_ln_gemm_f16(x, ga, be, 1e-5, W, 0, 0, q, M, C, C, C, C, C, C, 0, st())
+    wq_a, wkv = torch.zeros(nq, dtype=torch.uint8, device="cuda"), torch.empty(nkv, dtype=torch.uint8, device="cuda")
+    L.tcl_attention_pack_f16(q, C, Tq * C, kv, 2 * C, Lt * 2 * C, kv[:, :, C:], 2 * C, Lt * 2 * C, B, Hh, Tq, Lt, d, d ** -0.5, 1, 1, wq_a, wkv, st())
+    o_a = torch.empty(M, C, device="cuda", dtype=H)
+    L.tcl_attention_f16(q, C, Tq * C, 0, 0, 0, 0, 0, 0, o_a, C, Tq * C, B, Hh, Tq, Lt, d, d ** -0.5, 1, 4, wq_a, wkv, st())
+    # the fused route, into a panel whose padding rows carry a sentinel pattern of zeros
+    wq_b = torch.zeros(nq, dtype=torch.uint8, device="cuda")
+    L.tcl_ln_gemm_qpanel_f16(x, ga, be, 1e-5, W, M, Hh, d, Tq, C, C, d ** -0.5, wq_b, st())
+    o_b = torch.empty(M, C, device="cuda", dtype=H)
+    L.tcl_attention_f16(wq_b, C, Tq * C, 0, 0, 0, 0, 0, 0, o_b, C, Tq * C, B, Hh, Tq, Lt, d, d ** -0.5, 1, 4, wq_b, wkv, st())
+    torch.cuda.synchronize()
+    Tqp = (Tq + 255) // 256 * 256
+    pa = wq_a[:B * Hh * Tqp * 48 * 2].view(H).view(B, Hh, Tqp, 48)
+    pb = wq_b[:B * Hh * Tqp * 48 * 2].view(H).view(B, Hh, Tqp, 48)
+    assert torch.equal(pa[:, :, :Tq], pb[:, :, :Tq])                       # same bits in every written row, padding columns 40..47 zero in both
+    assert (pb[:, :, Tq:] == 0).all() and (pb[..., 40:] == 0).all()
+    assert torch.equal(o_a, o_b)
+    ref = F.scaled_dot_product_attention(*(t.float().view(B, -1, Hh, d).transpose(1, 2) for t in (q.view(B, Tq, C), kv[:, :, :C], kv[:, :, C:]))).transpose(1, 2).reshape(M, C)
+    assert rel(o_b, ref) < 3e-3
+
+
 def test_gemm_fused_geglu_configs(L):
     """GEGLU epilogue (64-row [32 value | 32 gate] groups) across tile configurations, incl. the 8-wave 256x256 / 128x256 kernels."""
     from tc_light_amd.unet import _geglu_rows

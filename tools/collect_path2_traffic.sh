@@ -27,11 +27,17 @@ for reuse, key in (("0.02", "bench_codebook_regime"), ("0.7", "realistic_codeboo
     # the script runs the stage twice (one warm call, one timed call): 2 x it iterations.  Per-iteration kernels = the ones tcl_unique_tensor_opt
     # launches inside its loop (path2.hip); its one-off kernels (scatter-mean init, ids check, final catch-up of all rows, final gather) and the
     # script's own input synthesis (torch kernels) are listed apart and NOT part of the per-iteration figure
-    LOOP = ("k_adam_touched_frame", "k_adam_catchup_frame", "k_gather_codebook", "k_codebook_bwd", "k_flow_loss", "k_pixel_losses", "k_ssim_fwd",
-            "k_ssim_bwd", "k_pool2", "k_msssim_finalize", "k_loss_finalize", "k_adam(", "__amd_rocclr_fillBufferAligned")
+    LOOP = ("k_adam_touched_frame", "k_adam_catchup_frame", "k_adam_step_rows_lazy", "k_gather_codebook", "k_codebook_bwd", "k_flow_loss", "k_pixel_losses",
+            "k_ssim_fwd", "k_ssim_bwd", "k_pool2", "k_msssim_finalize", "k_loss_finalize", "k_adam(", "__amd_rocclr_fillBufferAligned")
     is_loop = lambda k: any(t in k for t in LOOP)
     byts = lambda k: (2 * f[k] + w[k]) * 1024
-    fix = lambda k: (2 * it) / (2 * it + 2) if "k_gather_codebook" in k else 1.0        # (the final full gather of each call is a one-off)
+    lazy = any("k_gather_codebook_lazy" in k for k in f)
+    # the plain gather: per iteration 2 b = 32 frames (dense schedule; the lazy schedule gathers with k_gather_codebook_lazy), plus ONE final gather of all
+    # 300 frames per call (a one-off, 300 / 32 iteration-gathers worth of bytes)
+    def fix(k):
+        if k.startswith("k_gather_codebook("):
+            return 0.0 if lazy else (2 * it) / (2 * it + 2 * 300 / 32)
+        return 1.0
     tot = sum(byts(k) * fix(k) for k in f if is_loop(k)) / (2 * it)
     once = sum(byts(k) for k in f if not is_loop(k) and k.startswith(("k_", "void k_"))) / 2
     per_kernel = {k: {"launches": n[k], "MB_per_iteration": byts(k) * fix(k) / (2 * it) / 1e6} for k in sorted(f, key=lambda k: -byts(k)) if is_loop(k)}

@@ -1056,10 +1056,12 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         while (b < batch && bi[b] >= 0) { nvalid += bi[b] > 0; ++b; }
         TCL_CHECK_ARG(b > 0);
         const int* cidx = d_cat + (size_t)it * 2 * batch;
-        // lazy: the mini-batch's rows are read as they will stand after the steps they skipped (1 .. it): replayed in the gather's registers, and
-        // again -- together with the gradient step it + 1 -- in the step kernel, the only one that writes them (round 5; rounds 3-4 ran a
-        // catch-up launch of their own first: TCL_ADAM_LAZY_V1=1 keeps that schedule for A/B -- same bits)
-        static const bool v1 = getenv("TCL_ADAM_LAZY_V1") && atoi(getenv("TCL_ADAM_LAZY_V1")) != 0;
+        // lazy, default (rounds 3-5): a catch-up launch brings the mini-batch's rows to step `it` (writes them), the gather reads them, the step kernel
+        // applies step it + 1.  TCL_ADAM_LAZY_V1=0 (round 5, opt-in): ONE visit with a write -- the gather replays the skipped steps in registers and the step
+        // kernel replays them again before the gradient step.  Same bits; 208 -> 156 B of traffic per row, but the replay ARITHMETIC doubles: with the bench's
+        // ~19 skipped steps per visit (one visit per epoch) the two kernels take 2.2 ms against 2.0 for catch-up + gather + step
+        // (profiles/r5_bench_kernel_stats.txt vs r4), while on a 60-iteration run (short replays) it wins 5 % (profiles/r5_ab_path2_lazy_single_visit.txt).
+        static const bool v1 = !(getenv("TCL_ADAM_LAZY_V1") && atoi(getenv("TCL_ADAM_LAZY_V1")) == 0);
         const LazyGather lz = {m, v, bc1, bc2, t_last, it, lr};
         if (lazy && v1)
             hipLaunchKernelGGL(k_adam_catchup_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, m, v, it, lr, 0.9f, 0.999f,

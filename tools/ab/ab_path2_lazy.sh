@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: stage 2's lazy Adam with ONE visit per row and iteration (default) vs rounds 3-4's catch-up launch + gather + step (TCL_ADAM_LAZY_V1=1),
+# round 5: stage 2's lazy Adam with ONE visit per row and iteration (TCL_ADAM_LAZY_V1=0, opt-in) vs rounds 3-4's catch-up launch + gather + step (default),
 # bench codebook regime (reuse 0.02: K ~ N H W) and realistic track lengths (0.7: dense Adam, unaffected), 300 x 1280 x 720, 60 iterations
 for r in 1 2; do for v in 0 1; do
   echo "== TCL_ADAM_LAZY_V1=$v (round $r)"

@@ -867,7 +867,10 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st);
     }
     const int nblk = B * H * nqb;
-    const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > 512) ? 512 : nblk;      // gated exact pass: one resident round of blocks walks the flags
+    // gated exact pass: a small grid of blocks walks the flags (normally none is set: what the launch costs is the DISPATCH of its 222-VGPR / 66-KiB blocks --
+    // 57 us with one block per flag (round 3), 56 us in the pass with one resident round of 512 (round 4); TCL_FLASH_GATE_BLOCKS, default 64, round 5)
+    static const int gate_blocks = getenv("TCL_FLASH_GATE_BLOCKS") ? atoi(getenv("TCL_FLASH_GATE_BLOCKS")) : 64;
+    const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > gate_blocks) ? gate_blocks : nblk;
     hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>), dim3(grid), dim3(64 * NW), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;

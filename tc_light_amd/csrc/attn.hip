@@ -868,8 +868,9 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     }
     const int nblk = B * H * nqb;
     // gated exact pass: a small grid of blocks walks the flags (normally none is set: what the launch costs is the DISPATCH of its 222-VGPR / 66-KiB blocks --
-    // 57 us with one block per flag (round 3), 56 us in the pass with one resident round of 512 (round 4); TCL_FLASH_GATE_BLOCKS, default 64, round 5)
-    static const int gate_blocks = getenv("TCL_FLASH_GATE_BLOCKS") ? atoi(getenv("TCL_FLASH_GATE_BLOCKS")) : 64;
+    // 57 us with one block per flag (round 3), 56 us in the pass with one resident round of 512 (round 4).  Round 5 measured smaller grids
+    // (TCL_FLASH_GATE_BLOCKS, profiles/r5_ab_flash_gate.txt): 64 blocks the same call rate as 512, 16 blocks 1.4 % SLOWER -- the pass is not dispatch-bound)
+    static const int gate_blocks = getenv("TCL_FLASH_GATE_BLOCKS") ? atoi(getenv("TCL_FLASH_GATE_BLOCKS")) : 512;
     const int grid = (D == 40 && QB == 2 && !SPEC && flags && nblk > gate_blocks) ? gate_blocks : nblk;
     hipLaunchKernelGGL((k_flash<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>), dim3(grid), dim3(64 * NW), lds, st, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, nqb, flags, nblk);
     if (prof) { (void)hipEventRecord(e1, st); g_prof.ev.push_back(e0); g_prof.ev.push_back(e1); if (count) { const double fl = 4.0 * B * H * (double)Tq * Tk * d; g_prof.flops += fl; g_prof.launches++; if (fl > g_prof.bigfl) { g_prof.bigfl = fl; g_prof.big[0] = B; g_prof.big[1] = H; g_prof.big[2] = Tq; g_prof.big[3] = Tk; } } }

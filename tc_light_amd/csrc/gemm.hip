@@ -227,11 +227,14 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void k_gemm(const _Float16* _
 // Out-of-range rows / conv taps fetch from a zero page.  ~110 VGPRs and 34.8 KiB LDS -> 4 blocks per CU.
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[64];
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+// QP (round 5): the per-chunk QKV projection of a merging transformer block with its result written straight into the attention panels (QkvPanel,
+// gemm_conv.h) -- M tiles are cut per batch entry (tile rows = 128 consecutive tokens of ONE entry = two whole 64-key V^T tiles), the epilogue sends
+// the Q / K row chunks to their head-major rows and transposes the V columns through the staged C tile; k_pack_qkv and the [M, 3 C] round trip go.
+template <int BM, int BN, int WM, int WN, int STAGES, int QP = 0>
 __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128 ? 2 : BM * BN < 128 * 128 ? 4 : (STAGES == 2 ? 4 : 3)) void k_gemm_dma(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                      const _Float16* __restrict__ bias, const _Float16* __restrict__ resid,
                                                      _Float16* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
-                                                     ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part, int xcd_n) {
+                                                     ConvP cp, int tiles_m, int tiles_n, int nk_per, float* __restrict__ part, int xcd_n, QkvPanel qp) {
     constexpr int KB = 32;                                  // K per step
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int ROWB = KB * 2;                            // bytes per LDS row (64)
@@ -255,7 +258,13 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
         tm = j % tiles_m; tn = (j / tiles_m) * 8 + xcd;
     }
     if (tm >= tiles_m || tn >= tiles_n) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0 = tm * BM, mlim = M, qb = 0, qtl = 0;
+    if constexpr (QP) {                       // tile tm = (entry qb, token tile qtl): rows [qb T + qtl BM, ...) of that entry only
+        const int tpe = (qp.T + BM - 1) / BM;
+        qb = tm / tpe; qtl = tm - qb * tpe;
+        m0 = qb * qp.T + qtl * BM; mlim = (qb + 1) * qp.T;
+    }
+    const int n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
 
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + (wid * A_IT + i) * 16 + rr;
-        a_ok[i] = m < M;
+        a_ok[i] = m < mlim;
         if (!cp.conv) { a_off[i] = (long)m * lda; a_oy[i] = a_ox[i] = 0; }
         else {
             int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;
@@ -393,6 +402,59 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
         }
     }
     __syncthreads();
+    if constexpr (QP) {
+        static_assert(!QP || BM == 128, "two whole 64-key tiles per M tile");
+        const int Cc = qp.H * qp.d, t0 = qtl * BM;
+        constexpr int CPRQ = BN / 8;
+#pragma unroll
+        for (int i = 0; i < BM * CPRQ / 256; ++i) {                 // Q and K: 8-column row chunks (d % 8 == 0: a chunk never straddles a head or a projection)
+            const int c = tid + 256 * i, row = c / CPRQ, c8 = (c % CPRQ) * 8, t = t0 + row, n = n0 + c8;
+            if (t >= qp.T || n >= 2 * Cc) continue;
+            half8 v = *(const half8*)(Cs + row * CS + c8);
+            const int which = n >= Cc, nn = n - which * Cc, head = nn / qp.d, dd = nn - head * qp.d;
+            const long bh = (long)qb * qp.H + head;
+            if (!which) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (_Float16)((float)v[q] * qp.qscale);
+                *(half8*)(qp.qp + (bh * qp.Tqp + t) * qp.DP + dd) = v;
+            } else {
+                _Float16* kr = qp.kp + (bh * qp.Tkp + t) * qp.KS;
+                *(half8*)(kr + dd) = v;
+                if (qp.one_col >= 0 && dd + 8 == qp.d) { half8 o1; o1[0] = (_Float16)1.f;
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) o1[q] = (_Float16)0.f;
+                    *(half8*)(kr + qp.one_col) = o1; }
+            }
+        }
+        const int v_lo = max(n0, 2 * Cc), v_hi = min(n0 + BN, N);   // the V columns of this tile -> V^T tile rows, 8 permuted key positions per store
+        if (v_lo < v_hi) {
+            const int nt = qp.Tkp / 64, items = (v_hi - v_lo) * 16;
+            for (int it = tid; it < items; it += 256) {
+                const int col = it >> 4, kq = (it >> 3) & 1, p8 = it & 7;
+                const int kt = qtl * (BM / 64) + kq;
+                if (kt >= nt) continue;
+                const int n = v_lo + col, nn = n - 2 * Cc, head = nn / qp.d, dd = nn - head * qp.d;
+                _Float16* tile = qp.vt + (((long)qb * qp.H + head) * nt + kt) * qp.vtile;
+                const _Float16* src = Cs + (kq * 64) * CS + (n - n0);
+                const bool ones_too = dd + 1 == qp.d && qp.DPV > qp.d;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    if (pass == 1 && !ones_too) break;
+                    const int rowi = pass ? qp.d : dd;
+                    const int sk = (qp.skew && (((rowi & 15) + 4) & 8)) ? 16 : 0;
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ps = (8 * p8 + j) ^ sk, r = (ps & ~12) | ((ps & 4) << 1) | ((ps & 8) >> 1);
+                        const bool ok = kt * 64 + r < qp.T;
+                        o[j] = ok ? (pass ? (_Float16)1.f : src[r * CS]) : (_Float16)0.f;
+                    }
+                    *(half8*)(tile + rowi * 72 + 8 * p8) = o;
+                }
+            }
+        }
+        return;
+    }
     if (act == 2) {
         constexpr int CPH = BN / 16;
 #pragma unroll
@@ -447,8 +509,24 @@ static int launch_gemm_dma(const _Float16* A, const _Float16* W, const _Float16*
     const int xcd_n = xcd_mode < 0 ? (N > M) : xcd_mode;
     const int grid = (xcd_n ? cdiv(tn, 8) * 8 * tm : cdiv(tm, 8) * 8 * tn) * splits;
     hipLaunchKernelGGL((k_gemm_dma<BM, BN, WM, WN, STAGES>), dim3(grid), dim3(256), lds, st, A, W, bias, resid, C, M, N, K, lda, ldw, ldc, ldr,
-                       act, cp, tm, tn, nk_per, part, xcd_n);
+                       act, cp, tm, tn, nk_per, part, xcd_n, QkvPanel{});
     if (part) hipLaunchKernelGGL(k_splitk_finalize, dim3(stream_grid((long)M * N, 256, 4)), dim3(256), 0, st, part, splits, bias, resid, C, M, N, ldc, ldr, act);
+    return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
+}
+
+// the QKV projection of ne x T merged tokens into the attention panels: 128 x 128 tiles, M tiles per batch entry, no split-K
+int gemm_dma_qkv_panels(const _Float16* A, const _Float16* W, int ne, int K, int lda, int ldw, const QkvPanel& qp, hipStream_t st) {
+    constexpr int BM = 128, BN = 128, STAGES = 3;
+    const int N = 3 * qp.H * qp.d, M = ne * qp.T;
+    if (K % 32 != 0 || (lda & 7) || (ldw & 7) || qp.d % 8 != 0 || qp.Tkp % 64 != 0) return TCL_EINVAL;
+    const int tm = ne * cdiv(qp.T, BM), tn = cdiv(N, BN);
+    const size_t ops = (size_t)STAGES * (BM + BN) * 64, cs = (size_t)BM * (BN + 8) * 2, lds = ops > cs ? ops : cs;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_dma<BM, BN, 2, 2, STAGES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    ConvP cp = {};
+    const int grid = cdiv(tm, 8) * 8 * tn;
+    hipLaunchKernelGGL((k_gemm_dma<BM, BN, 2, 2, STAGES, 1>), dim3(grid), dim3(256), lds, st, A, W, (const _Float16*)nullptr, (const _Float16*)nullptr,
+                       (_Float16*)nullptr, M, N, K, lda, ldw, N, N, 0, cp, tm, tn, K / 32, (float*)nullptr, 0, qp);
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 

@@ -10,6 +10,13 @@ struct ConvP {
     float sy, sx;        // Hin/Hup, Win/Wup (nearest source scale, PyTorch 'nearest' convention)
 };
 
+// QKV projection written straight into the flash kernel's panels (round 5; csrc/attn.hip documents the layouts): Qp [ne, H, Tqp, DP] pre-scaled,
+// Kp [ne, H, Tkp, KS] (+ ones column `one_col` when >= 0), Vt [ne, H, Tkp / 64, vtile halves]: DPV rows of 72 halves per 64-key tile, keys permuted
+// (bits 2 <-> 3 of the in-tile key index), rows 4..11 (mod 16) skewed by 16 positions when `skew`, row d = ones over the valid keys when DPV > d.
+// Everything the epilogue does not write (padding rows / columns, rows d + 1 .. DPV - 1) is expected to be ZERO already.
+struct QkvPanel { _Float16 *qp, *kp, *vt; int T, Tqp, Tkp, H, d, DP, KS, DPV, vtile, one_col, skew; float qscale; };
+int gemm_dma_qkv_panels(const _Float16* A, const _Float16* W, int ne, int K, int lda, int ldw, const QkvPanel& qp, hipStream_t st);
+
 // K order of the implicit 3x3 convolution, shared by every GEMM kernel so that they all accumulate in the same order (results are
 // bit-identical across tile configurations).  The weights are stored tap-major ([Cout][9][Cin]); the kernels WALK K channel-slice-major
 // when Cin % 64 == 0: the 64-wide step q covers channels (q/9)*64.. of tap q%9, so nine consecutive steps re-touch the same input rows

@@ -289,6 +289,21 @@ class UNetEngine:
             cache[key] = torch.zeros(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
         return cache[key]
 
+    def _attn_panels(self, ne, Hh, T, d):
+        """Zero-initialised Q and K / V^T panel workspaces per (entries, heads, merged length, head_dim), reused by every chunk and block that meets the shape
+        again (all on the main stream: stream order serialises writer and readers).  tcl_gemm_qkv_panels_f16 never writes the panels' padding, which therefore
+        stays zero.  The merged lengths of a clip are a handful of values (chunk lengths 1..4 x which side of the global merge is src); the cache is bounded."""
+        key = (ne, Hh, T, d)
+        cache = self.__dict__.setdefault("_panel_cache", {})
+        hit = cache.pop(key, None)
+        if hit is None:
+            nq, nkv = self.L.tcl_attention_q_bytes(ne, Hh, T, d), self.L.tcl_attention_kv_bytes(ne, Hh, T, d)
+            while cache and sum(a.numel() + b.numel() for a, b in cache.values()) + nq + nkv > (24 << 30):
+                cache.pop(next(iter(cache)))                      # oldest first (dict order = insertion / last use)
+            hit = (torch.zeros(nq, dtype=torch.uint8, device=self.dev), torch.zeros(nkv, dtype=torch.uint8, device=self.dev))
+        cache[key] = hit
+        return hit
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             prio = os.environ.get("TCL_SIDE_PRIO", "")
@@ -337,11 +352,19 @@ class UNetEngine:
             # The matching chain (bank order, dozens of small launches per chunk) runs on a side stream, ahead of the attention of the
             # chunks already matched: only merge(c) -> merge(c+1) and merge(c) -> attention(c) are real dependencies, so the small
             # kernels of chunk c+1 fill the tails of chunk c's QKV GEMM / flash launches instead of serialising with them.
+            qkv_panel = d in (40, 80) and os.environ.get("TCL_QKV_PANEL", "1") != "0"
+
             def attend(F, off, merged, unm, T, qkv, packed):
-                if qkv is None:
-                    qkv = o.gemm(merged, blk["qkv"], M=ne * T)
-                a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half,
-                                packed=packed)
+                if qkv is None and qkv_panel:
+                    # the QKV projection writes the attention panels itself (gemm.hip QP epilogue): no [ne*T, 3C] tensor, no pack launch
+                    wq, wkv = self._attn_panels(ne, Hd, T, d)
+                    L.tcl_gemm_qkv_panels_f16(merged, blk["qkv"], ne, T, Hd, d, C, C, C, d ** -0.5, wq, wkv, stream())
+                    a = o.attention(wq, 3 * C, T * 3 * C, None, 0, 0, None, 0, 0, ne, Hd, T, T, d, pair=pair_half, packed=(wq, wkv))
+                else:
+                    if qkv is None:
+                        qkv = o.gemm(merged, blk["qkv"], M=ne * T)
+                    a = o.attention(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hd, T, T, d, pair=pair_half,
+                                    packed=packed)
                 y = o.gemm(a, blk["o1"][0], blk["o1"][1], M=ne * T)
                 self.tome.unmerge_add(h[off * N:], xbs, y, T, unm, F * N, C, ne)  # u_a(...) + x (patch.py:178-179)
                 self._fl(2.0 * 2 * T * C * C * 4 + 4.0 * 2 * T * T * C, 2.0 * ne * T * C * C * 4 + 4.0 * ne * T * T * C)

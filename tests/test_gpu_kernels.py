@@ -536,6 +536,39 @@ def test_ln_gemm_qpanel_equals_linear_then_pack(L):
     assert rel(o_b, ref) < 3e-3
 
 
+@pytest.mark.parametrize("d,T,ne", [(40, 345, 2), (40, 1411, 2), (80, 333, 2), (40, 777, 1), (80, 64, 1)])
+def test_gemm_qkv_panels_equal_gemm_then_pack(L, d, T, ne):
+    """Round 5: attn1's QKV projection written straight into the Q / K / V^T panels (tcl_gemm_qkv_panels_f16: M tiles per batch entry, Q / K row chunks
+    re-addressed, V transposed through the staged C tile with the panel's key permutation, skew and ones row) against tcl_gemm_f16 +
+    tcl_attention_pack_f16: EVERY byte of the three panels equal -- lengths that are no multiple of 64 / 128 / 256, an entry boundary inside an M tile of
+    the plain GEMM, a single entry (the CFG pair's shared prefix) -- and the attention on them bit-identical."""
+    g = torch.Generator(device="cuda").manual_seed(100 + d + T)
+    Hh = 8
+    C = Hh * d
+    x = torch.randn(ne * T, C, device="cuda", generator=g).to(H)
+    W = (torch.randn(3 * C, C, device="cuda", generator=g) / C ** 0.5).to(H)
+    nq, nkv = L.tcl_attention_q_bytes(ne, Hh, T, d), L.tcl_attention_kv_bytes(ne, Hh, T, d)
+    qkv = torch.empty(ne * T, 3 * C, device="cuda", dtype=H)
+    L.tcl_gemm_f16(x, W, 0, 0, qkv, ne * T, 3 * C, C, C, C, 3 * C, 3 * C, 0, st())
+    wq_a, wkv_a = torch.zeros(nq, dtype=torch.uint8, device="cuda"), torch.zeros(nkv, dtype=torch.uint8, device="cuda")
+    L.tcl_attention_pack_f16(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hh, T, T, d, d ** -0.5, 1, 1, wq_a, wkv_a, st())
+    wq_b, wkv_b = torch.zeros(nq, dtype=torch.uint8, device="cuda"), torch.zeros(nkv, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                           # twice into the same workspace: the second call must leave the same bytes
+        L.tcl_gemm_qkv_panels_f16(x, W, ne, T, Hh, d, C, C, C, d ** -0.5, wq_b, wkv_b, st())
+    torch.cuda.synchronize()
+    Tqp, DP = (T + 255) // 256 * 256, (d + 15) // 16 * 16
+    nqp = ne * Hh * Tqp * DP * 2
+    assert torch.equal(wq_a[:nqp], wq_b[:nqp]), "Q panel"
+    assert torch.equal(wkv_a, wkv_b), "K / V^T panels"
+    oa, ob = torch.empty(ne * T, C, device="cuda", dtype=H), torch.empty(ne * T, C, device="cuda", dtype=H)
+    L.tcl_attention_f16(qkv, 3 * C, T * 3 * C, 0, 0, 0, 0, 0, 0, oa, C, T * C, ne, Hh, T, T, d, d ** -0.5, 1, 4, wq_a, wkv_a, st())
+    L.tcl_attention_f16(wq_b, 3 * C, T * 3 * C, 0, 0, 0, 0, 0, 0, ob, C, T * C, ne, Hh, T, T, d, d ** -0.5, 1, 4, wq_b, wkv_b, st())
+    assert torch.equal(oa, ob)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().view(ne, T, Hh, d).transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(ne * T, C)
+    assert rel(ob, ref) < 3e-3
+
+
 def test_gemm_fused_geglu_configs(L):
     """GEGLU epilogue (64-row [32 value | 32 gate] groups) across tile configurations, incl. the 8-wave 256x256 / 128x256 kernels."""
     from tc_light_amd.unet import _geglu_rows

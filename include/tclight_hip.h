@@ -164,11 +164,13 @@ int tcl_ln_gemm_qpanel_f16(const void* x, const void* gamma, const void* beta, f
                            float scale, void* ws_q, hipStream_t st);
 /* attn1's fused QKV projection of a VidToMe-merging block written straight into the attention panels (patch.py:170-176: `attn1(norm_hidden_states)` over the
  * merged tokens; diffusers Attention.to_q / to_k / to_v, no bias): x [ne*T, K] @ W[3 H d, K]^T -> Qp / Kp / V^T panels in ws_q / ws_kv with exactly the
+ * (entry b's rows start x_bs elements after entry b-1's; row_index != NULL: token t is row row_index[t] of its entry's block -- the merge map of
+ * merge.py's "replace" mode applied in the operand load instead of by a gather pass)
  * bytes tcl_attention_pack_f16 would have written from the [ne*T, 3 H d] product (d = 40 or 80).  ws_q / ws_kv: tcl_attention_q_bytes / _kv_bytes(ne, H, T, d),
  * ZERO-INITIALISED once per (ne, H, T, d) by the caller and reusable by stream-ordered calls of that shape (padding is never written).  Follow with
  * tcl_attention_f16(..., pack_kv = 4 (pre-packed) [| 2], ws_q, ws_kv). */
-int tcl_gemm_qkv_panels_f16(const void* x, const void* W, int ne, int T, int H, int d, int K, int ldx, int ldw, float scale, void* ws_q, void* ws_kv,
-                            hipStream_t st);
+int tcl_gemm_qkv_panels_f16(const void* x, long x_bs, const int* row_index, const void* W, int ne, int T, int H, int d, int K, int ldx, int ldw, float scale,
+                            void* ws_q, void* ws_kv, hipStream_t st);
 int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st);
 /* diffusers GEGLU: in [rows, 2D] -> out [rows, D] = in[:, :D] * gelu(in[:, D:]) (exact erf gelu). */
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st);

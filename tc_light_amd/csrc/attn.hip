@@ -965,18 +965,20 @@ int tcl_attention_pack_f16(const void* q, int ldq, long qbs, const void* k, int 
     TCL_CHECK_ARG(!(pack_kv & 1) || (k && v));
     return attention_pack(q, ldq, qbs, k, ldk, kbs, v, ldv, vbs, B, H, Tq, Tk, d, scale, kv_div, 1, pack_kv & 1, ws_q, ws_kv, st);
 }
+// x: entry b's rows start at x + b * x_bs (elements); row_index (may be NULL): merged token t = row row_index[t] of the entry's block -- the VidToMe merge
+// map applied in the GEMM's operand load (merge.py "replace" mode is a pure gather), so the merged sequence needs no tensor of its own.
 // attn1's QKV projection of ne x T merged tokens (x [ne*T, K] @ W[3 H d, K]^T, no bias: diffusers Attention.to_q / to_k / to_v) written straight into
 // the panels tcl_attention_pack_f16 would have produced from its [ne*T, 3 H d] output -- same bits in every byte the pack writes.  ws_q / ws_kv must have
 // been ZERO-INITIALISED once for this (ne, H, T, d) (sizes: tcl_attention_q_bytes / _kv_bytes) and may be reused by stream-ordered calls of the same shape:
 // padding rows / columns and the V^T rows above the ones row are never written.  Follow with tcl_attention_f16(..., pack_kv = 4 | pair bit, ws_q, ws_kv).
-int tcl_gemm_qkv_panels_f16(const void* x, const void* W, int ne, int T, int H, int d, int K, int ldx, int ldw, float scale, void* ws_q, void* ws_kv,
-                            hipStream_t st) {
+int tcl_gemm_qkv_panels_f16(const void* x, long x_bs, const int* row_index, const void* W, int ne, int T, int H, int d, int K, int ldx, int ldw, float scale,
+                            void* ws_q, void* ws_kv, hipStream_t st) {
     TCL_CHECK_ARG(x && W && ws_q && ws_kv && ne > 0 && T > 0 && H > 0 && (d == 40 || d == 80) && K > 0 && K % 32 == 0 && ldx >= K && ldw >= K);
     const int Tqp = rup(T, 256), Tkp = rup(T, 64), DP = rup(d, 16), KS = DP + 8, DPV = d == 40 && !flash_pv32() ? TCL_DPV40 : rup(d, 32);
     _Float16* Kp = (_Float16*)ws_kv;
     _Float16* Vt = Kp + (((size_t)ne * H * Tkp * KS + 511) / 512) * 512;
     const QkvPanel qp = {(_Float16*)ws_q, Kp, Vt, T, Tqp, Tkp, H, d, DP, KS, DPV, vt_tile_halves(DPV), d == 40 ? 40 : -1, d == 40 && !flash_pv32() ? 1 : 0,
-                         scale * 1.4426950408889634f};
+                         scale * 1.4426950408889634f, row_index, x_bs};
     TclProfScope ps(TCL_PROF_GEMM, st, 2.0 * ne * T * 3.0 * H * d * K);
     return gemm_dma_qkv_panels((const _Float16*)x, (const _Float16*)W, ne, K, ldx, ldw, qp, st);
 }

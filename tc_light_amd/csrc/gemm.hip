@@ -276,6 +276,10 @@ __global__ __launch_bounds__(256, BM * BN >= 256 * 256 ? 1 : BM * BN > 128 * 128
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + (wid * A_IT + i) * 16 + rr;
         a_ok[i] = m < mlim;
+        if constexpr (QP) {                                   // token t of entry qb: row aidx[t] (or t) of the entry's source block
+            const int t = qtl * BM + (wid * A_IT + i) * 16 + rr;
+            a_off[i] = (long)qb * qp.a_bs + (long)(qp.aidx && a_ok[i] ? qp.aidx[t] : t) * lda; a_oy[i] = a_ox[i] = 0;
+        } else
         if (!cp.conv) { a_off[i] = (long)m * lda; a_oy[i] = a_ox[i] = 0; }
         else {
             int hw = cp.Hout * cp.Wout, b = m / hw, r = m - b * hw, oy = r / cp.Wout, ox = r - oy * cp.Wout;

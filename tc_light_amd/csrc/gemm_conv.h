@@ -14,7 +14,9 @@ struct ConvP {
 // Kp [ne, H, Tkp, KS] (+ ones column `one_col` when >= 0), Vt [ne, H, Tkp / 64, vtile halves]: DPV rows of 72 halves per 64-key tile, keys permuted
 // (bits 2 <-> 3 of the in-tile key index), rows 4..11 (mod 16) skewed by 16 positions when `skew`, row d = ones over the valid keys when DPV > d.
 // Everything the epilogue does not write (padding rows / columns, rows d + 1 .. DPV - 1) is expected to be ZERO already.
-struct QkvPanel { _Float16 *qp, *kp, *vt; int T, Tqp, Tkp, H, d, DP, KS, DPV, vtile, one_col, skew; float qscale; };
+// aidx (may be null): token t of an entry reads row aidx[t] of that entry's source block (the VidToMe merge map: the merged sequence is never gathered into
+// a tensor of its own); a_bs: elements between the entries' source blocks.
+struct QkvPanel { _Float16 *qp, *kp, *vt; int T, Tqp, Tkp, H, d, DP, KS, DPV, vtile, one_col, skew; float qscale; const int* aidx; long a_bs; };
 int gemm_dma_qkv_panels(const _Float16* A, const _Float16* W, int ne, int K, int lda, int ldw, const QkvPanel& qp, hipStream_t st);
 
 // K order of the implicit 3x3 convolution, shared by every GEMM kernel so that they all accumulate in the same order (results are

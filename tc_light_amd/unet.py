@@ -356,9 +356,11 @@ class UNetEngine:
 
             def attend(F, off, merged, unm, T, qkv, packed):
                 if qkv is None and qkv_panel:
-                    # the QKV projection writes the attention panels itself (gemm.hip QP epilogue): no [ne*T, 3C] tensor, no pack launch
+                    # the QKV projection writes the attention panels itself (gemm.hip QP epilogue): no [ne*T, 3C] tensor, no pack launch; a lazily merged
+                    # sequence (block, entry stride, merge map) is gathered by the GEMM's operand load
                     wq, wkv = self._attn_panels(ne, Hd, T, d)
-                    L.tcl_gemm_qkv_panels_f16(merged, blk["qkv"], ne, T, Hd, d, C, C, C, d ** -0.5, wq, wkv, stream())
+                    src, sbs, idx = merged if isinstance(merged, tuple) else (merged, T * C, 0)
+                    L.tcl_gemm_qkv_panels_f16(src, sbs, idx, blk["qkv"], ne, T, Hd, d, C, C, C, d ** -0.5, wq, wkv, stream())
                     a = o.attention(wq, 3 * C, T * 3 * C, None, 0, 0, None, 0, 0, ne, Hd, T, T, d, pair=pair_half, packed=(wq, wkv))
                 else:
                     if qkv is None:
@@ -386,7 +388,8 @@ class UNetEngine:
             def hand_over(merged, unm, qkv, packed, ev):
                 if two:
                     main.wait_event(ev)
-                    for tns in ((qkv,) + packed) if qkv_side else (merged,):       # allocated on the side stream's pool, read on the main stream
+                    held = ((qkv,) + packed) if qkv_side else ((merged[0], merged[2]) if isinstance(merged, tuple) else (merged,))
+                    for tns in held:                                               # allocated on the side stream's pool, read on the main stream
                         tns.record_stream(main)
                     if unm is not None:
                         unm.record_stream(main)
@@ -394,8 +397,8 @@ class UNetEngine:
             for ci, F in enumerate(Fs):
                 self.tome.select_chunk(ci, chunks)
                 with torch.cuda.stream(side):
-                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs,
-                                                             metric=m1[off * N:] if m1 is not None else None, ne=ne)     # merged [ne, T, C]
+                    merged, unm, T = self.tome.compute_merge(p, n1[off * N:], F, N, C, xbs=xbs, metric=m1[off * N:] if m1 is not None else None, ne=ne,
+                                                             lazy_merged=qkv_panel and not qkv_side and os.environ.get("TCL_MERGE_LAZY", "1") != "0")     # merged [ne, T, C]
                     qkv = packed = None
                     if qkv_side:
                         qkv = o.gemm(merged, blk["qkv"], M=ne * T)

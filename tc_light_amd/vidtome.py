@@ -180,14 +180,17 @@ class VidToMe:
             return False
         return int(math.ceil(math.sqrt((self.size[0] * self.size[1]) // N))) <= self.args["max_downsample"]
 
-    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None, metric=None, ne=2):
+    def compute_merge(self, name, x, F, N, C, _unused=None, xbs=None, metric=None, ne=2, lazy_merged=False):
         """x: norm1 output of one chunk: the unconditional [F*N, C] rows at x, the conditional ones xbs elements further (default
         F*N*C: a contiguous [2F, N, C] == joined [2, F*N, C]); metric: x's cosine-normalised rows in the same layout if norm1 wrote them
         (unet.py: tcl_layernorm_metric_f16), else None.  ne = 1: x holds ONE entry because the caller knows the pair to be identical (the
         classifier-free-guidance pair before the first text cross-attention, unet.py): with equal scores in both entries the matching picks
         the first one (lowest concatenated dst index), i.e. exactly the single-entry matching -- same maps, merged tokens and bank [1, T, C].
         Returns None when this block is not merged, else
-        (merged [2,T,C], unm int32 [F*N] ([2, F*N] without align_batch) or None for identity, T)."""
+        (merged [2,T,C], unm int32 [F*N] ([2, F*N] without align_batch) or None for identity, T).
+        lazy_merged=True (unet.py, round 5): where the merged sequence is a gather of the [local | bank] block by a map shared by the entries, it is NOT
+        materialised -- `merged` is then the tuple (block [ne, Tcat, C], Tcat*C, map int32 [T]) for a consumer that applies the map in its operand load
+        (tcl_gemm_qkv_panels_f16)."""
         a = self.args
         if not self.merges(N):
             return None
@@ -243,8 +246,11 @@ class VidToMe:
         L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, ne, Tb, C, stream())
         mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
                                      a["global_merge_ratio"], affine=(src_len, 0, src_len), ne=ne)
-        merged = torch.empty(ne, Tm, C, dtype=H16, device=self.dev)
-        self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C, ne)
+        if lazy_merged and mrg2.dim() == 1:
+            merged = (cat, T * C, mrg2)
+        else:
+            merged = torch.empty(ne, Tm, C, dtype=H16, device=self.dev)
+            self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C, ne)
         unm = self._compose(unm2, unm1, loff, F * N)                            # 2s-unmerge then the randframe unmerges (func_warper(u_ls[::-1]))
         bmap = self._compose(mrg2, unm2[..., loff:].contiguous() if unm2.dim() == 2 else unm2[loff:], 0, TL)     # bank <- u(merged_tokens) (patch.py:80)
         nb_ = torch.empty(ne, TL, C, dtype=H16, device=self.dev)

@@ -554,8 +554,16 @@ def test_gemm_qkv_panels_equal_gemm_then_pack(L, d, T, ne):
     L.tcl_attention_pack_f16(qkv, 3 * C, T * 3 * C, qkv[:, C:], 3 * C, T * 3 * C, qkv[:, 2 * C:], 3 * C, T * 3 * C, ne, Hh, T, T, d, d ** -0.5, 1, 1, wq_a, wkv_a, st())
     wq_b, wkv_b = torch.zeros(nq, dtype=torch.uint8, device="cuda"), torch.zeros(nkv, dtype=torch.uint8, device="cuda")
     for _ in range(2):                                           # twice into the same workspace: the second call must leave the same bytes
-        L.tcl_gemm_qkv_panels_f16(x, W, ne, T, Hh, d, C, C, C, d ** -0.5, wq_b, wkv_b, st())
+        L.tcl_gemm_qkv_panels_f16(x, T * C, 0, W, ne, T, Hh, d, C, C, C, d ** -0.5, wq_b, wkv_b, st())
+    # the same through a row index: the merged tokens as rows idx[t] of a larger per-entry source block (the VidToMe merge map in the operand load)
+    Ts = T + 57
+    idx = torch.randperm(Ts, device="cuda", generator=g)[:T].to(torch.int32).contiguous()
+    src = torch.randn(ne, Ts, C, device="cuda", generator=g).to(H)
+    src[:, idx.long()] = x.view(ne, T, C)
+    wq_c, wkv_c = torch.zeros(nq, dtype=torch.uint8, device="cuda"), torch.zeros(nkv, dtype=torch.uint8, device="cuda")
+    L.tcl_gemm_qkv_panels_f16(src, Ts * C, idx, W, ne, T, Hh, d, C, C, C, d ** -0.5, wq_c, wkv_c, st())
     torch.cuda.synchronize()
+    assert torch.equal(wq_c[:ne * Hh * ((T + 255) // 256 * 256) * ((d + 15) // 16 * 16) * 2], wq_b[:ne * Hh * ((T + 255) // 256 * 256) * ((d + 15) // 16 * 16) * 2]) and torch.equal(wkv_c, wkv_b), "row-index form"
     Tqp, DP = (T + 255) // 256 * 256, (d + 15) // 16 * 16
     nqp = ne * Hh * Tqp * DP * 2
     assert torch.equal(wq_a[:nqp], wq_b[:nqp]), "Q panel"

@@ -396,7 +396,9 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
 // directly.  Integer sums: the result does not depend on which way an addend took, nor on the order -- and with W % 64 == 0 the waves
 // cover the same 64-pixel row segments as the untiled form (TILED == false, kept for A/B: TCL_FLOW_TILED=0), so the two agree bit for bit.
 #define FT_W 64
+#ifndef FT_H
 #define FT_H 16
+#endif
 #define FT_SL 5
 #define FT_WX (FT_W + 3 + FT_SL)
 #define FT_WY (FT_H + 3 + FT_SL)

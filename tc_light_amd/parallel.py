@@ -90,6 +90,8 @@ class Dist:
         gather_frames(produce(0, n_local), n_total)."""
         if self.world == 1:
             return produce(0, n_local)
+        if n_local < 1:
+            raise ValueError(f"gather_frames_pipelined: rank {self.rank} holds no frame ({n_total} frames over {self.world} ranks): every rank needs at least one")
         nmax = -(-n_total // self.world)
         nslab = -(-nmax // slab)
         works, outs, shape = [], [], None

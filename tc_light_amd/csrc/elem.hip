@@ -88,27 +88,45 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
                                                   const float* __restrict__ sums, const _Float16* __restrict__ gamma,
                                                   const _Float16* __restrict__ beta, float inv_n, float eps, int G, _Float16* __restrict__ y, int HW,
                                                   int silu, _Float16* __restrict__ yraw) {
+    // Round 5: a thread OWNS one 8-channel chunk and walks rows (threads of a block: [rows rp][chunks cw], consecutive lanes = consecutive chunks of a
+    // row), so the per-channel scale / shift -- two statistics loads, two rsqrt, gamma / beta -- is built once per thread instead of once per 16 bytes
+    // (the first form spent ~140 vector instructions per chunk, most of them on constants: it was as VALU-bound as HBM-bound).  Same arithmetic per element.
     const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8, cpg = C / G;
-    const long total = (long)HW * nchunk;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        long row = i / nchunk; int ch = (int)(i % nchunk) * 8;
-        const _Float16* p = ch < C1 ? x1 + ((long)b * HW + row) * C1 + ch : x2 + ((long)b * HW + row) * C2 + (ch - C1);
-        h8 v = *(const h8*)p, o;
+    const int cw = nchunk < 256 ? nchunk : 256, rp = 256 / cw;
+    const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+    if (tr >= rp) return;
+    for (int c0 = 0; c0 < nchunk; c0 += cw) {
+        const int chunk = c0 + tc;
+        if (chunk >= nchunk) continue;
+        const int ch = chunk * 8;
         const h8 ga = *(const h8*)(gamma + ch), be = *(const h8*)(beta + ch);
         const int g0 = ch / cpg, g1 = (ch + 7) / cpg, split = (g0 + 1) * cpg - ch;      // channels j >= split belong to g1
         const float2 s0 = *(const float2*)(sums + ((long)b * G + g0) * 2), s1 = *(const float2*)(sums + ((long)b * G + g1) * 2);
         const float m0 = s0.x * inv_n, m1 = s1.x * inv_n;
         const float r0 = rsqrtf(fmaxf(s0.y * inv_n - m0 * m0, 0.f) + eps), r1 = rsqrtf(fmaxf(s1.y * inv_n - m1 * m1, 0.f) + eps);
+        float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float mean = j < split ? m0 : m1, rstd = j < split ? r0 : r1;
-            const float sc = rstd * (float)ga[j], sh = (float)be[j] - mean * sc;
-            float a = (float)v[j] * sc + sh;
-            if (silu) a = a / (1.f + __expf(-a));
-            o[j] = (_Float16)a;
+            sc[j] = rstd * (float)ga[j]; sh[j] = (float)be[j] - mean * sc[j];
         }
-        *(h8*)(y + ((long)b * HW + row) * C + ch) = o;
-        if (yraw) *(h8*)(yraw + ((long)b * HW + row) * C + ch) = v;      // the un-normalised concat, for the ResNet block's 1x1 shortcut (round 5: was a pass of its own)
+        const bool first = ch < C1;
+        const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
+        const int ld = first ? C1 : C2;
+        _Float16* yb = y + (long)b * HW * C + ch;
+        _Float16* rb = yraw ? yraw + (long)b * HW * C + ch : nullptr;
+        for (int row = blockIdx.x * rp + tr; row < HW; row += gridDim.x * rp) {
+            const h8 v = *(const h8*)(base + (long)row * ld);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = (float)v[j] * sc[j] + sh[j];
+                if (silu) a = a / (1.f + __expf(-a));
+                o[j] = (_Float16)a;
+            }
+            *(h8*)(yb + (long)row * C) = o;
+            if (rb) *(h8*)(rb + (long)row * C) = v;      // the un-normalised concat, for the ResNet block's 1x1 shortcut (round 5: was a pass of its own)
+        }
     }
 }
 
@@ -452,8 +470,9 @@ int tcl_groupnorm_concat_f16(const void* x1, int C1, const void* x2, int C2, con
     float* part = (float*)ws; float* sums = part + (size_t)B * gn_blocks_cap(B) * 64 * 2;
     hipLaunchKernelGGL(k_gn_stats, dim3(blocks, B), dim3(256), 0, st, (const _Float16*)x1, C1, (const _Float16*)x2, C2, HW, groups, rpb, part);
     hipLaunchKernelGGL(k_gn_reduce, dim3(B), dim3(1024), 0, st, part, blocks, groups, sums);
-    long chunks = (long)HW * (C / 8);
-    hipLaunchKernelGGL(k_gn_apply, dim3(stream_grid(chunks, 256, 2) > 2048 ? 2048 : stream_grid(chunks, 256, 2), B), dim3(256), 0, st,
+    const int cwa = C / 8 < 256 ? C / 8 : 256, rpa = 256 / cwa;             // k_gn_apply: rows per block step; ~8 rows per thread, at most 2048 blocks per sample
+    int gab = cdiv(HW, (long)rpa * 8); if (gab > 2048) gab = 2048;
+    hipLaunchKernelGGL(k_gn_apply, dim3(gab, B), dim3(256), 0, st,
                        (const _Float16*)x1, C1, (const _Float16*)x2, C2, sums, (const _Float16*)gamma, (const _Float16*)beta,
                        1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu, (_Float16*)yraw);
     TCL_LAUNCH_RET();

@@ -34,14 +34,24 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
             const bool first = ch < C1;
             const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
             const int ld = first ? C1 : C2;
-            for (int row = r0 + tr; row < r1; row += rp) {
-                h8 v = *(const h8*)(base + (long)row * ld);
+            // 4 loads in flight per thread (the first form waited for every 16-byte load before issuing the next: latency-bound at ~3.8 TB/s): full
+            // groups of 4 rows without a guard, then the tail row by row -- the accumulation order (row by row, channel by channel) is unchanged
+            auto acc = [&](const h8& v) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float f = (float)v[j], f2 = f * f;
                     sa += f; qa += f2; sl += f * wlo[j]; ql += f2 * wlo[j];
                 }
+            };
+            int row = r0 + tr;
+            for (; row + 3 * rp < r1; row += 4 * rp) {
+                h8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(base + (long)(row + u * rp) * ld);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc(v[u]);
             }
+            for (; row < r1; row += rp) acc(*(const h8*)(base + (long)row * ld));
         }
         __syncthreads();
         ps[threadIdx.x][0] = sl; ps[threadIdx.x][1] = ql; ps[threadIdx.x][2] = sa - sl; ps[threadIdx.x][3] = qa - ql;
@@ -84,13 +94,18 @@ __global__ __launch_bounds__(1024) void k_gn_reduce(const float* __restrict__ pa
 }
 // pass 2: y = act((x - mean) * rstd * gamma + beta) with the per-(batch, group) statistics folded in per 8-channel chunk (a chunk
 // touches at most two groups); also materialises the channel concat.
+template <bool SILU, bool RAW>
 __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x1, int C1, const _Float16* __restrict__ x2, int C2,
                                                   const float* __restrict__ sums, const _Float16* __restrict__ gamma,
                                                   const _Float16* __restrict__ beta, float inv_n, float eps, int G, _Float16* __restrict__ y, int HW,
-                                                  int silu, _Float16* __restrict__ yraw) {
+                                                  _Float16* __restrict__ yraw) {
     // Round 5: a thread OWNS one 8-channel chunk and walks rows (threads of a block: [rows rp][chunks cw], consecutive lanes = consecutive chunks of a
     // row), so the per-channel scale / shift -- two statistics loads, two rsqrt, gamma / beta -- is built once per thread instead of once per 16 bytes
     // (the first form spent ~140 vector instructions per chunk, most of them on constants: it was as VALU-bound as HBM-bound).  Same arithmetic per element.
+    // Round 5, second pass: the row walk keeps GN_U loads in flight per thread (the ISA of the first form was load -> s_waitcnt vmcnt(0) -> 8 branches on
+    // the run-time `silu` -> store: ONE 16-byte load in flight per thread = 32 KB per CU, ~4 TB/s by Little's law at 2 us of loaded HBM latency);
+    // full groups of GN_U rows run without any guard (a guard at the store made hipcc sink each load into its guarded region again), the tail row by row.
+    constexpr int GN_U = 4;
     const int b = blockIdx.y, C = C1 + C2, nchunk = C / 8, cpg = C / G;
     const int cw = nchunk < 256 ? nchunk : 256, rp = 256 / cw;
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
@@ -114,19 +129,28 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
         const _Float16* base = first ? x1 + (long)b * HW * C1 + ch : x2 + (long)b * HW * C2 + (ch - C1);
         const int ld = first ? C1 : C2;
         _Float16* yb = y + (long)b * HW * C + ch;
-        _Float16* rb = yraw ? yraw + (long)b * HW * C + ch : nullptr;
-        for (int row = blockIdx.x * rp + tr; row < HW; row += gridDim.x * rp) {
-            const h8 v = *(const h8*)(base + (long)row * ld);
+        _Float16* rb = RAW ? yraw + (long)b * HW * C + ch : nullptr;
+        const int step = gridDim.x * rp;
+        auto apply = [&](const h8& v, int r) {
             h8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float a = (float)v[j] * sc[j] + sh[j];
-                if (silu) a = a / (1.f + __expf(-a));
+                if (SILU) a = a / (1.f + __expf(-a));
                 o[j] = (_Float16)a;
             }
-            *(h8*)(yb + (long)row * C) = o;
-            if (rb) *(h8*)(rb + (long)row * C) = v;      // the un-normalised concat, for the ResNet block's 1x1 shortcut (round 5: was a pass of its own)
+            *(h8*)(yb + (long)r * C) = o;
+            if (RAW) *(h8*)(rb + (long)r * C) = v;      // the un-normalised concat, for the ResNet block's 1x1 shortcut (round 5: was a pass of its own)
+        };
+        int row = blockIdx.x * rp + tr;
+        for (; row + (GN_U - 1) * step < HW; row += GN_U * step) {      // full groups: no guard anywhere, the GN_U loads are issued back to back
+            h8 v[GN_U];
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) v[u] = *(const h8*)(base + (long)(row + u * step) * ld);
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) apply(v[u], row + u * step);
         }
+        for (; row < HW; row += step) apply(*(const h8*)(base + (long)row * ld), row);
     }
 }
 
@@ -134,54 +158,73 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
 // METRIC: also write the row's cosine-normalised form y / |y| for the VidToMe matching of this block (merge.py:84: metric / metric.norm()),
 // with exactly the arithmetic and summation order of merge.hip::k_tome_normalize on the f16 y -- same lane <-> chunk layout -- so the
 // matching sees the same bits as when it normalised the tokens itself (one launch and one read of the tokens less per chunk and block).
-template <bool METRIC>
+// Round 5, second pass: a wave takes LN_R consecutive rows and issues all their loads before the first reduction (the first form had one row per
+// wave and, for C = 320, ONE 16-byte load in flight on 40 of the 64 lanes: ~2.9 TB/s); NK = ceil(C / 512) chunk slots per lane is a template
+// parameter, so there is no branch around a load (chunk and row are clamped for the load, masked in the sums and at the store).  Per row the
+// arithmetic, the lane <-> chunk layout and the summation order are those of the first form: same bits.
+#define LN_R 4
+template <bool METRIC, int NK>
 __global__ __launch_bounds__(256) void k_layernorm(const _Float16* __restrict__ x, const _Float16* __restrict__ gamma,
                                                    const _Float16* __restrict__ beta, _Float16* __restrict__ y, _Float16* __restrict__ metric,
                                                    long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
+    if (row0 >= rows) return;
     const int nchunk = C / 8;
-    h8 v[4]; float s = 0.f;
+    bool ok[NK]; int off[NK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int ch = lane + 64 * k;
-        if (ch < nchunk) { v[k] = *(const h8*)(x + row * C + ch * 8);
+    for (int k = 0; k < NK; ++k) { const int ch = lane + 64 * k; ok[k] = ch < nchunk; off[k] = min(ch, nchunk - 1) * 8; }
+    h8 v[LN_R][NK];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[k][j]; }
+    for (int r = 0; r < LN_R; ++r) {
+        const _Float16* xr = x + min(row0 + r, rows - 1) * C;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) v[r][k] = *(const h8*)(xr + off[k]);
     }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
+    h8 g[NK], bt[NK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (lane + 64 * k < nchunk)
+    for (int k = 0; k < NK; ++k) { g[k] = *(const h8*)(gamma + off[k]); bt[k] = *(const h8*)(beta + off[k]); }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float d = (float)v[k][j] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
-    float q2 = 0.f;
+    for (int r = 0; r < LN_R; ++r) {
+        const long row = row0 + r;
+        float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int ch = lane + 64 * k;
-        if (ch < nchunk) {
-            h8 g = *(const h8*)(gamma + ch * 8), bt = *(const h8*)(beta + ch * 8), o;
+        for (int k = 0; k < NK; ++k)
+            if (ok[k])
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[k][j] - mean) * rstd * (float)g[j] + (float)bt[j]);
-            *(h8*)(y + row * C + ch * 8) = o;
+                for (int j = 0; j < 8; ++j) s += (float)v[r][k][j];
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            if (ok[k])
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float d = (float)v[r][k][j] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        float q2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[r][k][j] - mean) * rstd * (float)g[k][j] + (float)bt[k][j]);
+            if (ok[k] && row < rows) *(h8*)(y + row * C + off[k]) = o;
             if (METRIC) {
-                v[k] = o;
+                v[r][k] = o;
+                if (ok[k])
 #pragma unroll
-                for (int j = 0; j < 8; ++j) q2 += (float)o[j] * (float)o[j];
+                    for (int j = 0; j < 8; ++j) q2 += (float)o[j] * (float)o[j];
             }
         }
-    }
-    if (METRIC) {
-        const float nrm = (float)(_Float16)sqrtf(wave_sum(q2));
+        if (METRIC) {
+            const float nrm = (float)(_Float16)sqrtf(wave_sum(q2));
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (lane + 64 * k < nchunk) { h8 o;
+            for (int k = 0; k < NK; ++k) {
+                h8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[k][j] / nrm);
-                *(h8*)(metric + row * C + (lane + 64 * k) * 8) = o; }
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[r][k][j] / nrm);
+                if (ok[k] && row < rows) *(h8*)(metric + row * C + off[k]) = o;
+            }
+        }
     }
 }
 
@@ -443,6 +486,16 @@ __global__ void k_conv1x1_small(const _Float16* __restrict__ x, int ldi, const _
     }
 }
 
+template <bool METRIC>
+static void launch_layernorm(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st) {
+    const dim3 grid(cdiv(rows, 4 * LN_R)), blk(256);
+    const int nk = (C / 8 + 63) / 64;
+#define LN_GO(NK_) hipLaunchKernelGGL((k_layernorm<METRIC, NK_>), grid, blk, 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta, \
+                                      (_Float16*)y, (_Float16*)metric, rows, C, eps)
+    if (nk <= 1) LN_GO(1); else if (nk == 2) LN_GO(2); else if (nk == 3) LN_GO(3); else LN_GO(4);
+#undef LN_GO
+}
+
 extern "C" {
 
 int tcl_conv1x1_small_f16(const void* x, int ldi, const void* W, const void* b, void* y, int ldo, long M, int Ci, int Co, hipStream_t st) {
@@ -472,21 +525,22 @@ int tcl_groupnorm_concat_f16(const void* x1, int C1, const void* x2, int C2, con
     hipLaunchKernelGGL(k_gn_reduce, dim3(B), dim3(1024), 0, st, part, blocks, groups, sums);
     const int cwa = C / 8 < 256 ? C / 8 : 256, rpa = 256 / cwa;             // k_gn_apply: rows per block step; ~8 rows per thread, at most 2048 blocks per sample
     int gab = cdiv(HW, (long)rpa * 8); if (gab > 2048) gab = 2048;
-    hipLaunchKernelGGL(k_gn_apply, dim3(gab, B), dim3(256), 0, st,
-                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, sums, (const _Float16*)gamma, (const _Float16*)beta,
-                       1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, silu, (_Float16*)yraw);
+#define GN_APPLY(S_, R_) hipLaunchKernelGGL((k_gn_apply<S_, R_>), dim3(gab, B), dim3(256), 0, st, \
+                       (const _Float16*)x1, C1, (const _Float16*)x2, C2, sums, (const _Float16*)gamma, (const _Float16*)beta, \
+                       1.f / ((float)HW * (float)(C / groups)), eps, groups, (_Float16*)y, HW, (_Float16*)yraw)
+    if (silu) { if (yraw) GN_APPLY(true, true); else GN_APPLY(true, false); }
+    else { if (yraw) GN_APPLY(false, true); else GN_APPLY(false, false); }
+#undef GN_APPLY
     TCL_LAUNCH_RET();
 }
 int tcl_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long rows, int C, float eps, hipStream_t st) {
     TCL_CHECK_ARG(x && gamma && beta && y && rows > 0 && C % 8 == 0 && C <= 2048);
-    hipLaunchKernelGGL(k_layernorm<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
-                       (_Float16*)y, (_Float16*)nullptr, rows, C, eps);
+    launch_layernorm<false>(x, gamma, beta, y, nullptr, rows, C, eps, st);
     TCL_LAUNCH_RET();
 }
 int tcl_layernorm_metric_f16(const void* x, const void* gamma, const void* beta, void* y, void* metric, long rows, int C, float eps, hipStream_t st) {
     TCL_CHECK_ARG(x && gamma && beta && y && metric && rows > 0 && C % 8 == 0 && C <= 2048);
-    hipLaunchKernelGGL(k_layernorm<true>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (const _Float16*)beta,
-                       (_Float16*)y, (_Float16*)metric, rows, C, eps);
+    launch_layernorm<true>(x, gamma, beta, y, metric, rows, C, eps, st);
     TCL_LAUNCH_RET();
 }
 int tcl_geglu_f16(const void* in, void* out, long rows, int D, hipStream_t st) {

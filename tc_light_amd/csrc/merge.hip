@@ -16,24 +16,45 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 #define MS 72   // LDS row stride (halves) for a 64-wide K step
 
+// Round 5, second pass: 4 rows per wave with all their loads in flight before the first reduction, NK = ceil(C / 512) chunk slots per lane as a
+// template parameter (no branch around a load; chunk / row clamped for the load, masked in the sum and at the store) -- the first form had one
+// row per wave and one 16-byte load in flight on 40 of 64 lanes at C = 320.  Per row the same arithmetic and summation order: same bits
+// (and the same as elem.hip::k_layernorm<true>, which writes the metric of a block's norm1 output).
+template <int NK>
 __global__ __launch_bounds__(256) void k_tome_normalize(const _Float16* __restrict__ x, _Float16* __restrict__ y, long rows, int C) {
+    constexpr int NR = 4;
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
+    if (row0 >= rows) return;
     const int nchunk = C / 8;
-    half8 v[4]; float q = 0.f;
+    bool ok[NK]; int off[NK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (lane + 64 * k < nchunk) { v[k] = *(const half8*)(x + row * C + (lane + 64 * k) * 8);
+    for (int k = 0; k < NK; ++k) { const int ch = lane + 64 * k; ok[k] = ch < nchunk; off[k] = min(ch, nchunk - 1) * 8; }
+    half8 v[NR][NK];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q += (float)v[k][j] * (float)v[k][j]; }
-    const float nrm = (float)(_Float16)sqrtf(wave_sum(q));   // norm rounded to f16, then an f16 division
+    for (int r = 0; r < NR; ++r) {
+        const _Float16* xr = x + min(row0 + r, rows - 1) * C;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (lane + 64 * k < nchunk) { half8 o;
+        for (int k = 0; k < NK; ++k) v[r][k] = *(const half8*)(xr + off[k]);
+    }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[k][j] / nrm);
-            *(half8*)(y + row * C + (lane + 64 * k) * 8) = o; }
+    for (int r = 0; r < NR; ++r) {
+        const long row = row0 + r;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+            if (ok[k])
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q += (float)v[r][k][j] * (float)v[r][k][j];
+        const float nrm = (float)(_Float16)sqrtf(wave_sum(q));   // norm rounded to f16, then an f16 division
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)((float)v[r][k][j] / nrm);
+            if (ok[k] && row < rows) *(half8*)(y + row * C + off[k]) = o;
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned sortable16(_Float16 h) {
@@ -467,7 +488,12 @@ extern "C" {
 
 int tcl_tome_normalize_f16(const void* x, void* y, long rows, int C, hipStream_t st) {
     TCL_CHECK_ARG(x && y && rows > 0 && C % 8 == 0 && C <= 2048);
-    hipLaunchKernelGGL(k_tome_normalize, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
+    const int nk = (C / 8 + 63) / 64;
+    const dim3 grid(cdiv(rows, 16));
+    if (nk <= 1) hipLaunchKernelGGL(k_tome_normalize<1>, grid, dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
+    else if (nk == 2) hipLaunchKernelGGL(k_tome_normalize<2>, grid, dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
+    else if (nk == 3) hipLaunchKernelGGL(k_tome_normalize<3>, grid, dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
+    else hipLaunchKernelGGL(k_tome_normalize<4>, grid, dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, rows, C);
     TCL_LAUNCH_RET();
 }
 

@@ -157,6 +157,18 @@ __global__ void k_expo_fin(const fx_t* __restrict__ efx, const int* __restrict__
     if (i >= 12) return;
     for (int j = 0; j < rows; ++j) gexpo[(size_t)idx[j] * 12 + i] += fx_get(efx[(size_t)j * 12 + i], 1.f / FX_EXPO);
 }
+// Memory-level parallelism for k_codebook_bwd (round 5, second pass).  Its first form walked a thread's pixels one after the other, each a chain of
+// dependent round trips (index -> gradient / mask -> read-modify-write of the row), with the block count already at the occupancy limit.  Now a thread
+// takes P2_U pixels per trip and walks the chain ONCE for all of them; KEEP(x) pins a loaded value at its place in the program: hipcc otherwise sinks a
+// load whose only use sits behind a per-pixel guard into that guard, which serialises the round trips again.  18.7 -> 12.5 us per launch (x 32 per
+// iteration), same bits.  The same rewrite of the two lazy-Adam kernels (k_adam_catchup_frame / k_adam_touched_frame: index -> step counter -> atomic
+// claim -> 9-12 row loads) was measured and REVERTED: at K = 2.7e8 rows they get slower the more rows a thread has in flight -- 846 / 857 us per launch
+// at 1 pixel per trip, 868 / 940 at 2, 1060 / 997 at 4, 1916 / 1527 at 8 (profiles/r5b_prof_p2_adjacent.txt; pixels a grid stride or a block width
+// apart alike, profiles/r5b_prof_p2_stride.txt) -- they are bound by the scattered 4-byte traffic itself (atomics and 9-12 planes per row), not by latency.
+#ifndef P2_U
+#define P2_U 4
+#endif
+#define KEEP(x) asm volatile("" :: "v"(x))
 // out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
 // cmask (may be null): bit c of byte [j][p] = channel c of that pixel lies inside [0, 1] -- the clamp's gradient mask, handed to k_codebook_bwd so that it
 // need not gather the codebook row a second time (round 5: a third of that kernel's traffic).
@@ -181,30 +193,66 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
 // ATOMIC == true (ids that repeat inside a frame): all rows in one launch, float atomics, order not reproducible.
 // cmask != null (lazy schedule, round 5): the clamp test of the gathered value comes from the mask byte the lazy gather wrote (bit c: channel c
 // inside [0, 1]) -- the codebook row in memory may still be steps behind, and the mask saves this kernel's three feat reads per pixel.
+// The run-time-uniform choices (image or pre-image gradient, clamp mask or codebook read) are template parameters of the body: a per-load select on a
+// run-time condition, even a wave-uniform one, makes hipcc branch around each load and wait for it (cdna_hip_programming.md, trap (c)).
+template <bool ATOMIC, bool PRE, bool HASCM>
+__device__ __forceinline__ void codebook_bwd_body(const float* __restrict__ feat, const int* __restrict__ iv, const float* __restrict__ g,
+                                                  const fxq_t* __restrict__ gq, float pre_scale, float* __restrict__ gfeat, int P, size_t K,
+                                                  const unsigned char* __restrict__ cm) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int p0 = blockIdx.x * (blockDim.x * P2_U) + threadIdx.x; p0 < P; p0 += P2_U * stride) {
+        int px[P2_U]; bool in[P2_U]; size_t id[P2_U]; int mk[P2_U]; float gc[P2_U][3];
+#pragma unroll
+        for (int u = 0; u < P2_U; ++u) { in[u] = p0 + u * (int)blockDim.x < P; px[u] = in[u] ? p0 + u * (int)blockDim.x : p0; }
+#pragma unroll
+        for (int u = 0; u < P2_U; ++u) {
+            id[u] = (size_t)iv[px[u]];
+            mk[u] = HASCM ? cm[px[u]] : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gc[u][c] = PRE ? (float)gq[c * P + px[u]] * pre_scale : g[c * P + px[u]];
+        }
+        float fv[P2_U][3], old[P2_U][3];
+#pragma unroll
+        for (int u = 0; u < P2_U; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!HASCM) fv[u][c] = feat[c * K + id[u]];
+                if (!ATOMIC) old[u][c] = gfeat[c * K + id[u]];      // the ids of a frame are distinct: 12 independent read-modify-writes
+            }
+#pragma unroll
+        for (int u = 0; u < P2_U; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { if (!HASCM) KEEP(fv[u][c]); if (!ATOMIC) KEEP(old[u][c]); }
+#pragma unroll
+        for (int u = 0; u < P2_U; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                bool inr;
+                if (HASCM) inr = (mk[u] >> c) & 1;
+                else { const float v = fv[u][c] * SH_C0 + 0.5f; inr = v >= 0.f && v <= 1.f; }
+                if (in[u] && inr && gc[u][c] != 0.f) {
+                    if (ATOMIC) atomicAdd(gfeat + c * K + id[u], gc[u][c] * SH_C0);
+                    else gfeat[c * K + id[u]] = old[u][c] + gc[u][c] * SH_C0;
+                }
+            }
+    }
+}
 template <bool ATOMIC>
 __global__ void k_codebook_bwd(const float* __restrict__ feat, const int* __restrict__ inv, const int* __restrict__ fidx,
                                const float* __restrict__ gimg, const fxq_t* __restrict__ gpre, float pre_scale, const int* __restrict__ flow_shift,
                                int b, int j0, float* __restrict__ gfeat, int P, size_t K, const unsigned char* __restrict__ cmask) {
     const int j = j0 + blockIdx.y, f = fidx[j];
-    if (j >= b) pre_scale = __builtin_ldexpf(pre_scale, -flow_shift[fidx[j - b]]);
     const int* iv = inv + (size_t)f * P;
-    const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
-    const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
     const unsigned char* cm = cmask ? cmask + (size_t)j * P : nullptr;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        size_t id = (size_t)iv[p];
-        const int mk = cm ? cm[p] : 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float gc = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
-            bool inr;
-            if (cm) inr = (mk >> c) & 1;
-            else { const float v = feat[c * K + id] * SH_C0 + 0.5f; inr = v >= 0.f && v <= 1.f; }
-            if (inr && gc != 0.f) {
-                if (ATOMIC) atomicAdd(gfeat + c * K + id, gc * SH_C0);
-                else gfeat[c * K + id] += gc * SH_C0;
-            }
-        }
+    if (j < b) {
+        const float* g = gimg + (size_t)j * 3 * P;
+        if (cm) codebook_bwd_body<ATOMIC, false, true>(feat, iv, g, nullptr, 0.f, gfeat, P, K, cm);
+        else codebook_bwd_body<ATOMIC, false, false>(feat, iv, g, nullptr, 0.f, gfeat, P, K, cm);
+    } else {
+        pre_scale = __builtin_ldexpf(pre_scale, -flow_shift[fidx[j - b]]);
+        const fxq_t* gq = gpre + (size_t)(j - b) * 3 * P;
+        if (cm) codebook_bwd_body<ATOMIC, true, true>(feat, iv, nullptr, gq, pre_scale, gfeat, P, K, cm);
+        else codebook_bwd_body<ATOMIC, true, false>(feat, iv, nullptr, gq, pre_scale, gfeat, P, K, cm);
     }
 }
 // Are the ids of every frame distinct?  Per frame: every pixel writes its index into scratch[id], then checks that it is still there.

@@ -27,6 +27,10 @@ for stage in [int(v) for v in os.environ.get('P2_STAGES', '1,2').split(',')]:   
     f = (lambda: P.exposure_align(ds, sched, epochs=1, batch_size=16)) if stage == 1 else (lambda: P.unique_tensor_optimization(ds, inv, sched, batch_size=16, k=K))
     f(); torch.cuda.synchronize(); ds = P.OptDataset(ed, flows, masks, device="cuda")
     ds.flow_shift; torch.cuda.synchronize()              # (once per clip: the per-frame fixed-point scale of the flow scatter, not an iteration's work)
-    t0 = time.perf_counter(); f(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / len(sched)
+    t0 = time.perf_counter(); res = f(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / len(sched)
+    if os.environ.get("P2_DIGEST"):          # A/B of two library builds (TCL_LIB_PATH): the stage's outputs must agree bit for bit
+        import hashlib
+        hs = [hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:16] for t in (res if isinstance(res, (tuple, list)) else [res]) if torch.is_tensor(t)]
+        print(f"stage {stage} digest: {' '.join(hs)}")
     by = (2 * 60 * b * Pp) if stage == 1 else ((56 + 48 + 24) * b * Pp + 84 * K)
     print(f"stage {stage}: {n} frames {w}x{h}, K={K}: {dt * 1e3:.3f} ms/iteration, algorithmic {by / 1e9:.2f} GB/iteration -> {by / dt / 1e12:.2f} TB/s ({by / dt / 8e12 * 100:.1f} % of 8 TB/s)")

@@ -60,6 +60,10 @@ static Gauss11 make_gauss() {
 }
 
 #include "bicubic.h"
+#include <type_traits>
+// KEEP(x) pins a loaded value at its place in the program: hipcc otherwise sinks a load whose only use sits behind a guard into that guard
+// (a branch and a s_waitcnt of its own per load -- the loads of a thread then run one round trip after the other).
+#define KEEP(x) asm volatile("" :: "v"(x))
 
 __global__ void k_warp_fwd(const float* __restrict__ img, const float* __restrict__ flow, float* __restrict__ out,
                            int C, int H, int W, int flow_c) {
@@ -135,16 +139,21 @@ __global__ void k_exposure_bwd(const float* __restrict__ src, const int* __restr
     const float* s = src + (size_t)f * 3 * P;
     const float* g = j < b ? gimg + (size_t)j * 3 * P : nullptr;
     const fxq_t* gq = j < b ? nullptr : gpre + (size_t)(j - b) * 3 * P;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        float x[3] = {s[p], s[P + p], s[2 * P + p]};
+    // (image or pre-image gradient: decided once per block, outside the pixel loop -- a per-load select on a run-time condition is a branch and a wait per load)
+    auto body = [&](auto PRE) {
+        for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+            float x[3] = {s[p], s[P + p], s[2 * P + p]}, gv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float t = x[0] * m[c] + x[1] * m[4 + c] + x[2] * m[8 + c] + m[c * 4 + 3];
-            float gv = g ? g[c * P + p] : (float)gq[c * P + p] * pre_scale;
-            float gc = (t >= 0.f && t <= 1.f) ? gv : 0.f;
-            acc[c] += x[0] * gc; acc[4 + c] += x[1] * gc; acc[8 + c] += x[2] * gc; acc[c * 4 + 3] += gc;
+            for (int c = 0; c < 3; ++c) gv[c] = decltype(PRE)::value ? (float)gq[c * P + p] * pre_scale : g[c * P + p];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = x[0] * m[c] + x[1] * m[4 + c] + x[2] * m[8 + c] + m[c * 4 + 3];
+                float gc = (t >= 0.f && t <= 1.f) ? gv[c] : 0.f;
+                acc[c] += x[0] * gc; acc[4 + c] += x[1] * gc; acc[8 + c] += x[2] * gc; acc[c * 4 + 3] += gc;
+            }
         }
-    }
+    };
+    if (j < b) body(std::false_type{}); else body(std::true_type{});
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         float r = block_sum(acc[i], red);
@@ -168,7 +177,6 @@ __global__ void k_expo_fin(const fx_t* __restrict__ efx, const int* __restrict__
 #ifndef P2_U
 #define P2_U 4
 #endif
-#define KEEP(x) asm volatile("" :: "v"(x))
 // out[j] = clamp(SH2RGB(feat[inv[fidx[j]*P + p]])) (generate.py:499-501)
 // cmask (may be null): bit c of byte [j][p] = channel c of that pixel lies inside [0, 1] -- the clamp's gradient mask, handed to k_codebook_bwd so that it
 // need not gather the codebook row a second time (round 5: a third of that kernel's traffic).
@@ -176,16 +184,34 @@ __global__ void k_gather_codebook(const float* __restrict__ feat, const int* __r
                                   float* __restrict__ out, int P, size_t K, unsigned char* __restrict__ cmask) {
     const int j = blockIdx.y, f = fidx ? fidx[j] : j;
     const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const size_t id = (size_t)iv[p];
-        int mk = 0;
+    // 4 pixels per trip, a block width apart: 4 index loads, then the 12 row loads, in flight together (round 5, second pass; the first form walked
+    // index -> row pixel by pixel)
+    const int stride = gridDim.x * blockDim.x;
+    for (int p0 = blockIdx.x * (blockDim.x * 4) + threadIdx.x; p0 < P; p0 += 4 * stride) {
+        size_t id[4]; float fv[4][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float val = feat[c * K + id] * SH_C0 + 0.5f;
-            mk |= (val >= 0.f && val <= 1.f) ? (1 << c) : 0;
-            o[c * P + p] = fminf(fmaxf(val, 0.f), 1.f);
+        for (int u = 0; u < 4; ++u) id[u] = (size_t)iv[min(p0 + u * (int)blockDim.x, P - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fv[u][c] = feat[c * K + id[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) KEEP(fv[u][c]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * (int)blockDim.x;
+            if (p >= P) break;
+            int mk = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float val = fv[u][c] * SH_C0 + 0.5f;
+                mk |= (val >= 0.f && val <= 1.f) ? (1 << c) : 0;
+                o[c * P + p] = fminf(fmaxf(val, 0.f), 1.f);
+            }
+            if (cmask) cmask[(size_t)j * P + p] = (unsigned char)mk;
         }
-        if (cmask) cmask[(size_t)j * P + p] = (unsigned char)mk;
     }
 }
 // d(loss)/d(codebook): cat row j0 + blockIdx.y.  ATOMIC == false: the ids of one frame are distinct, so a launch over ONE row is a conflict-free
@@ -274,14 +300,19 @@ __global__ void k_pool2(const float* __restrict__ in, const int* __restrict__ fi
     float* o = out + (size_t)q * oh * ow;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < oh * ow; i += gridDim.x * blockDim.x) {
         int oy = i / ow, ox = i - oy * ow, y0 = 2 * oy - ph, x0 = 2 * ox - pw;
-        float a = 0.f;
+        float a = 0.f, vv[4]; bool ok[4];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 int y = y0 + dy, x = x0 + dx;
-                if (y >= 0 && y < h && x >= 0 && x < w) a += s[y * w + x];
+                vv[dy * 2 + dx] = s[min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];      // unconditional load, select behind it (a + 0 = a)
+                ok[dy * 2 + dx] = y >= 0 && y < h && x >= 0 && x < w;
             }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) KEEP(vv[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a += ok[k] ? vv[k] : 0.f;
         o[i] = a * 0.25f;
     }
 }
@@ -296,11 +327,18 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(const float* __restrict__ X, c
     __shared__ float red[16];
     const int q = blockIdx.z, oh = h - HALO, ow = w - HALO, tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const float* xp = X + (size_t)q * h * w; const float* yp = Y + (size_t)q * h * w;
-    for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
+    // staging: every load unconditional at a clamped address, the select behind it, the loop unrolled -- all of a thread's loads are in flight together
+    // (`in ? xp[..] : 0` was a branch and a wait per load: round 5, second pass)
+#pragma unroll
+    for (int i0 = 0; i0 < TIH * TIW; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        if (i0 + 256 > TIH * TIW && i >= TIH * TIW) break;
         int r = i / TIW, c = i - r * TIW, gy = ty0 + r, gx = tx0 + c;
         bool in = gy < h && gx < w;
-        sx[r][c] = in ? xp[gy * w + gx] : 0.f;
-        sy[r][c] = in ? yp[gy * w + gx] : 0.f;
+        const int a = min(gy, h - 1) * w + min(gx, w - 1);
+        const float vx = xp[a], vy = yp[a];
+        sx[r][c] = in ? vx : 0.f;
+        sy[r][c] = in ? vy : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < TIH * TW; i += 256) {
@@ -371,11 +409,15 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(const float* __restrict__ X, c
     __shared__ float hz[3][TIH][TW];
     const int q = blockIdx.z, oh = h - HALO, ow = w - HALO, tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const size_t mo = (size_t)q * oh * ow;
-    for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
+#pragma unroll
+    for (int i0 = 0; i0 < TIH * TIW; i0 += 256) {          // (unconditional clamped loads + selects, unrolled: as in k_ssim_fwd)
+        const int i = i0 + threadIdx.x;
+        if (i0 + 256 > TIH * TIW && i >= TIH * TIW) break;
         int r = i / TIW, c = i - r * TIW, my = ty0 - HALO + r, mx = tx0 - HALO + c;
         bool in = my >= 0 && my < oh && mx >= 0 && mx < ow;
-        size_t mi = mo + (size_t)my * ow + mx;
-        sm[0][r][c] = in ? mA[mi] : 0.f; sm[1][r][c] = in ? mB[mi] : 0.f; sm[2][r][c] = in ? mC[mi] : 0.f;
+        size_t mi = mo + (size_t)min(max(my, 0), oh - 1) * ow + min(max(mx, 0), ow - 1);
+        const float va = mA[mi], vb = mB[mi], vc = mC[mi];
+        sm[0][r][c] = in ? va : 0.f; sm[1][r][c] = in ? vb : 0.f; sm[2][r][c] = in ? vc : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < TIH * TW; i += 256) {
@@ -413,17 +455,25 @@ __global__ void k_pixel_losses(const float* __restrict__ img, const float* __res
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         int y = p / W, xx = p - y * W;
         float v = x[p];
-        float g = g1 ? 0.25f * g1[(size_t)q * h1 * w1 + (size_t)((y + (H & 1)) >> 1) * w1 + ((xx + (W & 1)) >> 1)] : 0.f;
+        // (g1 / t may be null: the load then goes to a valid dummy address of x and the select drops it -- no branch around a load)
+        const float g1v = (g1 ? g1 + (size_t)q * h1 * w1 : x)[(size_t)((y + (H & 1)) >> 1) * w1 + ((xx + (W & 1)) >> 1)];
+        const float tv = (t ? t : x)[p];
+        KEEP(g1v); KEEP(tv);
+        float g = g1 ? 0.25f * g1v : 0.f;
         if (coef_l1 != 0.f) {
-            float d = v - t[p];
+            float d = v - tv;
             s_l1 += fabsf(d);
             g += coef_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         }
         if (coef_tvh != 0.f) {
-            if (y > 0) { float d = v - x[p - W]; s_h += d * d; g += coef_tvh * 2.f * d; }
-            if (y < H - 1) g -= coef_tvh * 2.f * (x[p + W] - v);
-            if (xx > 0) { float d = v - x[p - 1]; s_w += d * d; g += coef_tvw * 2.f * d; }
-            if (xx < W - 1) g -= coef_tvw * 2.f * (x[p + 1] - v);
+            // the four neighbours are read unconditionally (clamped to p at the border) before the first is used: a load inside `if (y > 0)` is a branch
+            // and a wait of its own -- four dependent round trips per pixel in the first form (round 5, second pass); same arithmetic, same order
+            const float nu = x[y > 0 ? p - W : p], nd = x[y < H - 1 ? p + W : p], nl = x[xx > 0 ? p - 1 : p], nr = x[xx < W - 1 ? p + 1 : p];
+            KEEP(nu); KEEP(nd); KEEP(nl); KEEP(nr);
+            if (y > 0) { float d = v - nu; s_h += d * d; g += coef_tvh * 2.f * d; }
+            if (y < H - 1) g -= coef_tvh * 2.f * (nd - v);
+            if (xx > 0) { float d = v - nl; s_w += d * d; g += coef_tvw * 2.f * d; }
+            if (xx < W - 1) g -= coef_tvw * 2.f * (nr - v);
         }
         gimg[(size_t)q * P + p] = g;
     }
@@ -471,23 +521,34 @@ __device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const
     Tap t = make_tap(fl[pc], fl[P + pc], x, y, W, H);
     const float m = live ? mk[pc] : 0.f;
     float wv[3] = {0.f, 0.f, 0.f}, s = 0.f;
+    // The 16 x 3 tap reads go out UNCONDITIONALLY, all before the first is used: a tap outside the image reads a clamped address with weight 0 (wv + 0 * v
+    // = wv, bit for bit -- frames are finite), same tap order.  The first form skipped such taps with `continue`, which hipcc compiled to a branch and a
+    // s_waitcnt vmcnt(0) per tap: 16 dependent round trips per pixel (round 5, second pass; ISA of k_flow_loss<true>).
+    float pv[16][3], wt[16];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        int yy = t.y0 + jj; if (yy < 0 || yy >= H) continue;
+        const int yy = t.y0 + jj; const bool yok = yy >= 0 && yy < H; const int yc = min(max(yy, 0), H - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int xx = t.x0 + i; if (xx < 0 || xx >= W) continue;
-            float wt = t.wy[jj] * t.wx[i]; int a = yy * W + xx;
-            wv[0] += wt * pre[a]; wv[1] += wt * pre[P + a]; wv[2] += wt * pre[2 * P + a];
+            const int xx = t.x0 + i; const bool ok = yok && xx >= 0 && xx < W; const int a = yc * W + min(max(xx, 0), W - 1);
+            wt[jj * 4 + i] = ok ? t.wy[jj] * t.wx[i] : 0.f;
+            pv[jj * 4 + i][0] = pre[a]; pv[jj * 4 + i][1] = pre[P + a]; pv[jj * 4 + i][2] = pre[2 * P + a];
         }
     }
-    float gw[3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { wv[0] += wt[k] * pv[k][0]; wv[1] += wt[k] * pv[k][1]; wv[2] += wt[k] * pv[k][2]; }
+    float gw[3], iv[3], go[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { iv[c] = img[c * P + pc]; go[c] = gi[c * P + pc]; }      // (with the tap reads: pc is a valid address on dead lanes too)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) KEEP(go[c]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float d = wv[c] * m - img[c * P + pc] * m;
+        float d;
+        { _Pragma("clang fp contract(off)") d = wv[c] * m - iv[c] * m; }      // (two products and a difference in every instantiation: the sign of d is the gradient)
         s += fabsf(d);
         gw[c] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * m;              // 0 on dead lanes (m = 0); unscaled
-        if (live) gi[c * P + pc] -= gw[c] * scale;
+        if (live) gi[c * P + pc] = go[c] - gw[c] * scale;
     }
     // Scatter of d(loss)/d(warped) into the pre-image gradient: 16 taps x 3 channels per pixel.  Neighbouring pixels of a row whose taps
     // share the integer offset (dx, dy) hit neighbouring cells: lane l's tap i and lane l+i's tap 0 are the SAME cell, so the four
@@ -526,7 +587,7 @@ __device__ __forceinline__ float flow_pixel(const float* __restrict__ img, const
     return s;
 }
 template <bool TILED>
-__global__ __launch_bounds__(256) void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
+__global__ __launch_bounds__(256, 4) void k_flow_loss(const float* __restrict__ cat, const int* __restrict__ idx, const float* __restrict__ flows,
                                                    const float* __restrict__ masks, int b, int H, int W, float scale, float* __restrict__ gimg,
                                                    fxq_t* __restrict__ gpre, fx_t* __restrict__ acc, int tiles_x, const int* __restrict__ flow_shift) {
     __shared__ float red[16];

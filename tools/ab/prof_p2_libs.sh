@@ -12,7 +12,7 @@ for l in "$@"; do
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:-float(r["TotalDurationNs"]))
-for r in rows[:5]:
+for r in rows[:12]:
     print(f'{r["Name"][:60]:60s} {int(r["Calls"]):7d} {float(r["TotalDurationNs"])/1e6:10.2f} ms  avg {float(r["AverageNs"])/1e3:9.2f} us')
 PY
 done

@@ -727,6 +727,23 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
 // (tests/test_gpu_path2.py::test_stage2_lazy_adam_equals_dense); traffic per iteration ~ the mini-batch's rows instead of all K.
 // Rows are visited frame by frame (one launch per cat row, like k_codebook_bwd<false>): ids are distinct inside a frame, and a row shared by
 // two frames of the batch is handled by whichever launch comes first (the t_last test).
+// t_last[row] = the last step applied to the row, plus (round 5, second pass) bit 30 = the row is SHARED: more than one pixel of the clip maps to it, so two
+// frames of a mini-batch may reach it in one launch and it must be claimed with an atomic.  A row that a single pixel holds (a track of length one: 98 % of the
+// rows with the bench clip's ids) has nobody to race with: its counter is read and written with plain accesses.  Every pixel's atomic was what bound the two
+// visiting kernels -- ~17 G device-scope atomics per second on scattered addresses -- more than their 108 bytes per row.
+// The flags are built once per stage without atomics: every pixel writes its own number into a scratch word of its row (plane 0 of the still-zero gradient),
+// then every pixel looks whether its number survived; a pixel that finds another one marks the row (idempotent plain store).
+#define TL_SHARED 0x40000000
+#define TL_STEP(x) ((x) & 0x3fffffff)
+__global__ void k_tl_mark(const int* __restrict__ inv, size_t total, int* __restrict__ scratch) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) scratch[inv[i]] = (int)i + 1;
+}
+__global__ void k_tl_flag(const int* __restrict__ inv, size_t total, const int* __restrict__ scratch, int* __restrict__ t_last) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int id = inv[i];
+        if (scratch[id] != (int)i + 1) t_last[id] = TL_SHARED;
+    }
+}
 __device__ __forceinline__ void adam_replay(float (&p)[3], float (&m)[3], float (&v)[3], int from, int to, float lr, float b1, float b2, float eps,
                                             const float* __restrict__ bc1, const float* __restrict__ bc2) {
     if (m[0] == 0.f && m[1] == 0.f && m[2] == 0.f && v[0] == 0.f && v[1] == 0.f && v[2] == 0.f) return;      // never touched: every skipped step is a no-op
@@ -743,12 +760,19 @@ __device__ __forceinline__ void adam_replay(float (&p)[3], float (&m)[3], float 
 __global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                      float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto, float lr, float b1, float b2,
                                      float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    // a frame can sit in the cat list twice (as a current frame and as the previous frame of another slot): only its FIRST occurrence walks its pixels --
+    // with the unshared rows no longer claimed by an atomic, two blocks on the same pixel would both step its row
+    for (int q = 0; q < (int)blockIdx.y; ++q) if (fidx[q] == fidx[blockIdx.y]) return;
     const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        if (t_last[id] >= upto) continue;
-        const int tl = atomicMax(t_last + id, upto);
-        if (tl >= upto) continue;
+        const int raw = t_last[id];
+        if (TL_STEP(raw) >= upto) continue;
+        int tl = TL_STEP(raw);
+        if (raw & TL_SHARED) {                      // a track that other pixels of the clip share: claim it (one winner per launch)
+            tl = TL_STEP(atomicMax(t_last + id, TL_SHARED | upto));
+            if (tl >= upto) continue;
+        } else t_last[id] = upto;                   // a row only this pixel holds: nobody to race with, no atomic (98 % of the rows in the bench's regime)
         float pp[3], mm[3], vv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
@@ -762,10 +786,17 @@ __global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __r
 __global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                      float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
                                      float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    // a frame can sit in the cat list twice (as a current frame and as the previous frame of another slot): only its FIRST occurrence walks its pixels --
+    // with the unshared rows no longer claimed by an atomic, two blocks on the same pixel would both step its row
+    for (int q = 0; q < (int)blockIdx.y; ++q) if (fidx[q] == fidx[blockIdx.y]) return;
     const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        if (t_last[id] != step - 1 || atomicCAS(t_last + id, step - 1, step) != step - 1) continue;      // stepped by another frame of this mini-batch
+        const int raw = t_last[id];
+        if (TL_STEP(raw) != step - 1) continue;
+        if (raw & TL_SHARED) {
+            if (atomicCAS(t_last + id, TL_SHARED | (step - 1), TL_SHARED | step) != (TL_SHARED | (step - 1))) continue;      // stepped by another frame of this mini-batch
+        } else t_last[id] = step;                   // unshared row: no claim needed
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float pi = p[c * K + id], mi = m[c * K + id], vi = v[c * K + id];
@@ -785,7 +816,7 @@ __global__ void k_gather_codebook_lazy(const float* __restrict__ feat, const flo
     const int* iv = inv + (size_t)f * P; float* o = out + (size_t)j * 3 * P; unsigned char* cm = cmask + (size_t)j * P;
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        const int tl = t_last[id];
+        const int tl = TL_STEP(t_last[id]);
         float pp[3], mm[3], vv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp[c] = feat[c * K + id];
@@ -809,13 +840,20 @@ __global__ void k_gather_codebook_lazy(const float* __restrict__ feat, const flo
 __global__ void k_adam_step_rows_lazy(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                       float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
                                       float b1, float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
+    // a frame can sit in the cat list twice (as a current frame and as the previous frame of another slot): only its FIRST occurrence walks its pixels --
+    // with the unshared rows no longer claimed by an atomic, two blocks on the same pixel would both step its row
+    for (int q = 0; q < (int)blockIdx.y; ++q) if (fidx[q] == fidx[blockIdx.y]) return;
     const int* iv = inv + (size_t)fidx[blockIdx.y] * P;
     const float c1 = bc1[step], c2 = bc2[step];
     for (int px = blockIdx.x * blockDim.x + threadIdx.x; px < P; px += gridDim.x * blockDim.x) {
         const size_t id = (size_t)iv[px];
-        if (t_last[id] >= step) continue;
-        const int tl = atomicMax(t_last + id, step);
-        if (tl >= step) continue;                                  // stepped by another frame of this mini-batch
+        const int raw = t_last[id];
+        if (TL_STEP(raw) >= step) continue;
+        int tl = TL_STEP(raw);
+        if (raw & TL_SHARED) {
+            tl = TL_STEP(atomicMax(t_last + id, TL_SHARED | step));
+            if (tl >= step) continue;                              // stepped by another frame of this mini-batch
+        } else t_last[id] = step;
         float pp[3], mm[3], vv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
@@ -831,7 +869,7 @@ __global__ void k_adam_step_rows_lazy(const int* __restrict__ inv, const int* __
 __global__ void k_adam_catchup_all(size_t K, int* __restrict__ t_last, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, int upto,
                                    float lr, float b1, float b2, float eps, const float* __restrict__ bc1, const float* __restrict__ bc2) {
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < K; id += (size_t)gridDim.x * blockDim.x) {
-        const int tl = t_last[id];
+        const int tl = TL_STEP(t_last[id]);
         if (tl >= upto) continue;
         float pp[3], mm[3], vv[3];
 #pragma unroll
@@ -1159,6 +1197,11 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         std::vector<float> tab(2 * (size_t)(iters + 1), 1.f);                // bias corrections of steps 1 .. iters, as tcl_adam_step computes them
         for (int sidx = 1; sidx <= iters; ++sidx) { tab[sidx] = (float)(1.0 - pow((double)0.9f, sidx)); tab[iters + 1 + sidx] = (float)sqrt(1.0 - pow((double)0.999f, sidx)); }   // (double)b1 of the FLOAT b1, like tcl_adam_step
         if (hipMemsetAsync(t_last, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        const size_t total = (size_t)N * P;
+        TCL_CHECK_ARG(total < 0x7fffffff && iters < TL_SHARED);
+        hipLaunchKernelGGL(k_tl_mark, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (int*)g);          // g is all zero here and is zeroed again below
+        hipLaunchKernelGGL(k_tl_flag, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (const int*)g, t_last);
+        if (hipMemsetAsync(g, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
         if (upload_table(bc1, tab.data(), tab.size(), st) != TCL_OK) return TCL_ELAUNCH;
     }
     for (int it = 0; it < iters; ++it) {

@@ -616,10 +616,19 @@ __global__ __launch_bounds__(64 * NW, (MINB ? MINB : (QB == 1 && DP <= 80 && TPB
         // 222 VGPRs / 66 KiB LDS just to read one word each took 57 us per attention call on the main stream (1.6 s per 300-frame pass).  The
         // gated pass is launched with at most 512 blocks (one resident round); a block walks the flags of its stride class and runs the flagged ones.
         if (flags) {
-            for (int bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
-                if (!flags[bid]) continue;
-                flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
-                __syncthreads();                  // the next item re-uses the LDS ring
+            // Round 5, second pass: a block reads its flags 64 NW at a time (one load per thread, one round trip per window) instead of one after the other
+            // -- a block of a 16-block grid walked ~370 DEPENDENT L2 round trips, which is why small grids measured slower (profiles/r5_ab_flash_gate.txt);
+            // with the windowed scan a 32-block grid costs the same as 512 IN THE PASS too (profiles/r5c_ab_gate_inpass.txt: 33.12-33.14 s of denoise at
+            // 60 frames either way, 8 blocks +0.3 %): the ~52 us of this launch are not a wait for slots between the matching chain's blocks.  512 stays.
+            const int per = (nblk + (int)gridDim.x - 1) / (int)gridDim.x, lo = (int)blockIdx.x * per, hi = min(lo + per, nblk);
+            for (int base = lo; base < hi; base += 64 * NW) {
+                const int mine = base + (int)threadIdx.x < hi ? flags[base + threadIdx.x] : 0;
+                if (!__syncthreads_or(mine)) continue;
+                for (int bid = base; bid < min(base + 64 * NW, hi); ++bid) {          // (rare: some block of this window flagged an overflow)
+                    if (!flags[bid]) continue;
+                    flash_block<D, DP, DPV, QB, NSTG, TPB, MINB, SPEC, PVW, NW>(bid, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, kv_div, nqb, flags);
+                    __syncthreads();              // the next item re-uses the LDS ring
+                }
             }
             return;
         }

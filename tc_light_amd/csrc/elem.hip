@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const _Float16* __restrict__ x
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = *(const h8*)(base + (long)(row + u * rp) * ld);
 #pragma unroll
+                for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(v[u]));      // all four issued before the first is consumed (the scheduler otherwise trickles them in two at a time behind the serial sums)
+#pragma unroll
                 for (int u = 0; u < 4; ++u) acc(v[u]);
             }
             for (; row < r1; row += rp) acc(*(const h8*)(base + (long)row * ld));

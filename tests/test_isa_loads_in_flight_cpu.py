@@ -1,0 +1,70 @@
+"""ISA lint of the HBM-bound kernels (CPU: hipcc cross-compiles gfx950 without a GPU).
+
+Round 5's second pass found that hipcc SINKS a load whose only use sits behind a guard into that guard (a branch and an `s_waitcnt vmcnt(0)` of its own per
+load) and leaves one load in flight per loop trip where the source walks rows one by one: `k_flow_loss` ran its 16 x 3 bicubic taps as 16 dependent round trips
+per pixel.  The rewrites pin the loads (`KEEP`, clamped addresses, guard-free main loops); this test keeps them pinned: per kernel, the longest
+run of `global_load` instructions with no `s_waitcnt vmcnt(..)` in between must not fall below the number the source asks for -- a compiler or source change
+that serialises them again fails here, on the CPU, before anybody needs a profiler."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# (source, mangled-name prefix, loads that must be in flight together)
+CASES = [
+    ("path2.hip", "_Z11k_flow_lossILb1", 48),          # 16 taps x 3 channels (+ the owner-pixel read-modify-write) of one pixel
+    ("path2.hip", "_Z14k_codebook_bwdILb0", 12),       # 4 pixels x 3 channels of the gradient rows
+    ("path2.hip", "_Z17k_gather_codebookPK", 12),      # 4 pixels x 3 channels
+    ("path2.hip", "_Z7k_pool2", 4),                    # the 2 x 2 window
+    ("path2.hip", "_Z14k_pixel_losses", 3),            # the four TV neighbours (hipcc issues one of them with the pixel's own loads)
+    ("path2.hip", "_Z10k_ssim_fwd", 8),                # staging loop, unrolled: X and Y of four elements
+    ("elem.hip", "_Z10k_gn_applyILb1ELb0", 4),         # 4 rows per trip
+    ("elem.hip", "_Z10k_gn_stats", 4),
+    ("elem.hip", "_Z11k_layernormILb1ELi1", 4),        # 4 rows per wave (+ gamma / beta)
+    ("elem.hip", "_Z11k_layernormILb0ELi2", 8),        # 4 rows x 2 chunk slots
+    ("merge.hip", "_Z16k_tome_normalizeILi1", 4),
+]
+
+
+@pytest.fixture(scope="module")
+def asm():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = {}
+        for src in sorted({c[0] for c in CASES}):
+            dst = os.path.join(tmp, src + ".s")
+            procs[src] = (dst, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-comment", "-S", "--cuda-device-only", "-o", dst,
+                                                 os.path.join(ROOT, "tc_light_amd", "csrc", src)], stderr=subprocess.DEVNULL))
+        for src, (dst, p) in procs.items():
+            assert p.wait() == 0, f"hipcc -S failed on {src}"
+            out[src] = open(dst).read()
+    return out
+
+
+def longest_load_run(text, prefix):
+    m = re.search(r"^(%s\w*):" % re.escape(prefix), text, flags=re.M)
+    assert m, f"kernel {prefix}* not found in the assembly"
+    body = text[m.end():]
+    body = body[:body.index("s_endpgm")]
+    best = run = 0
+    for line in body.splitlines():
+        op = line.strip().split(" ")[0].split("\t")[0]
+        if op.startswith("global_load") and "lds" not in op:
+            run += 1
+            best = max(best, run)
+        elif op.startswith("s_waitcnt") and "vmcnt" in line:
+            run = 0
+    return best
+
+
+@pytest.mark.parametrize("src,prefix,need", CASES, ids=[c[1] for c in CASES])
+def test_loads_in_flight(asm, src, prefix, need):
+    got = longest_load_run(asm[src], prefix)
+    assert got >= need, f"{prefix}: longest run of global loads without a vmcnt wait is {got}, the source asks for {need} (loads sunk into their guards again?)"

@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const _Float16* __restrict__ x
             h8 v[GN_U];
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) v[u] = *(const h8*)(base + (long)(row + u * step) * ld);
+            // (the RAW form issues rows 3 and 4 behind the stores of rows 1 and 2; pinning all four ahead of the first store measured no gain -- 705 / 1 029 / 522 us
+            // against 709 / 1 035 / 533 pinned on one box, tools/micro/gn_raw_check.py -- the pass is at the HBM rate either way)
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) apply(v[u], row + u * step);
         }

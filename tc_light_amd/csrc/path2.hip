@@ -1198,10 +1198,12 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         for (int sidx = 1; sidx <= iters; ++sidx) { tab[sidx] = (float)(1.0 - pow((double)0.9f, sidx)); tab[iters + 1 + sidx] = (float)sqrt(1.0 - pow((double)0.999f, sidx)); }   // (double)b1 of the FLOAT b1, like tcl_adam_step
         if (hipMemsetAsync(t_last, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
         const size_t total = (size_t)N * P;
-        TCL_CHECK_ARG(total < 0x7fffffff && iters < TL_SHARED);
-        hipLaunchKernelGGL(k_tl_mark, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (int*)g);          // g is all zero here and is zeroed again below
-        hipLaunchKernelGGL(k_tl_flag, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (const int*)g, t_last);
-        if (hipMemsetAsync(g, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        TCL_CHECK_ARG(iters < TL_SHARED);
+        if (total < 0x7fffffff) {
+            hipLaunchKernelGGL(k_tl_mark, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (int*)g);      // g is all zero here and is zeroed again below
+            hipLaunchKernelGGL(k_tl_flag, dim3(stream_grid((long)total, 256, 4)), dim3(256), 0, st, unq_inv, total, (const int*)g, t_last);
+            if (hipMemsetAsync(g, 0, K * 4, st) != hipSuccess) return TCL_ELAUNCH;
+        } else if (hipMemsetD32Async((hipDeviceptr_t)t_last, TL_SHARED, K, st) != hipSuccess) return TCL_ELAUNCH;      // a clip of >= 2^31 pixels: the pixel numbers of the marking pass do not fit an int -- every row claimed with an atomic, as before
         if (upload_table(bc1, tab.data(), tab.size(), st) != TCL_OK) return TCL_ELAUNCH;
     }
     for (int it = 0; it < iters; ++it) {

@@ -254,6 +254,12 @@ int tcl_tome_match_affine_f16(const void* metric, long bstride, int Bt, int C, c
 int tcl_index_compose(const int* outer, const int* inner, int off, int n, int* out, hipStream_t st);
 /* out[b][p] = map[p] >= 0 ? s1[b][map[p]] : s2[b][~map[p]]  (merge in "replace" mode; map NULL = copy). */
 int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, const int* map, void* out, long bso, int Bt, int n, int C, hipStream_t st);
+/* Two row sets through one map: oa[b][p] = sa[b][map[p]], ob[b][p] = sb[b][map[p]] (map NULL = identity; sb / ob NULL = one set).  The VidToMe chain moves a
+ * token block and its cosine-normalised rows (the matching metric, merge.py:86-87) together: the survivors of the local merge go straight into their slot of the
+ * global match's [src | dst] block and the new bank (patch.py:76-80) into the block of the chunk that will meet it, so no concatenation copy
+ * (patch.py:62-70 `torch.cat`) and no second normalisation exist.  bs* / bo*: elements between batch entries. */
+int tcl_gather_rows_pair_f16(const void* sa, long bsa, const void* sb, long bsb, const int* map, void* oa, long boa, void* ob, long bob, int Bt, int n, int C,
+                             hipStream_t st);
 /* h[b][i] += y[b][map[i]]  (unmerge + residual add, patch.py:178-179). */
 int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st);
 

@@ -472,6 +472,34 @@ __global__ void k_gather_rows(const _Float16* __restrict__ s1, long bs1, const _
         *(half8*)(out + bb * bso + (long)p * C + c8) = *(const half8*)(src + c8);
     }
 }
+// TWO row sets through ONE map (round 6: a token block and its cosine-normalised twin travel together -- the local merge's survivors into their slot of
+// the next [src | dst] block, the new bank into the block of the chunk that will meet it; compute_merge keeps no `cat` copy and never normalises twice):
+// oa[bb][p] = sa[bb][map[p]], ob[bb][p] = sb[bb][map[p]]  (map NULL = identity).  blockIdx.z picks the pair; 4 rows per trip in flight.
+__global__ __launch_bounds__(256) void k_gather_rows_pair(const _Float16* __restrict__ sa, long bsa, const _Float16* __restrict__ sb, long bsb,
+                                                          const int* __restrict__ map, _Float16* __restrict__ oa, long boa, _Float16* __restrict__ ob,
+                                                          long bob, int n, int C) {
+    const int nchunk = C / 8, bb = blockIdx.y;
+    const _Float16* src = (blockIdx.z ? sb + bb * bsb : sa + bb * bsa);
+    _Float16* out = (blockIdx.z ? ob + bb * bob : oa + bb * boa);
+    const long total = (long)n * nchunk, step = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * step < total; i += 4 * step) {
+        int p[4], c8[4], m[4];
+        half8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long q = i + u * step; p[u] = (int)(q / nchunk); c8[u] = (int)(q % nchunk) * 8; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = map ? map[p[u]] : p[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(src + (long)m[u] * C + c8[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(half8*)(out + (long)p[u] * C + c8[u]) = v[u];
+    }
+    for (; i < total; i += step) {
+        const int p = (int)(i / nchunk), c8 = (int)(i % nchunk) * 8, m = map ? map[p] : p;
+        *(half8*)(out + (long)p * C + c8) = *(const half8*)(src + (long)m * C + c8);
+    }
+}
 // h[bb][i] += y[bb][map[i]]   (unmerge + residual)
 __global__ void k_gather_add_rows(_Float16* __restrict__ h, long bsh, const _Float16* __restrict__ y, long bsy, const int* __restrict__ map, int n, int C) {
     const int nchunk = C / 8, bb = blockIdx.y;
@@ -577,6 +605,14 @@ int tcl_gather_rows_f16(const void* s1, long bs1, const void* s2, long bs2, cons
     TCL_CHECK_ARG(s1 && out && Bt > 0 && n > 0 && C % 8 == 0);
     int g = stream_grid((long)n * (C / 8), 256, 2); if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_gather_rows, dim3(g, Bt), dim3(256), 0, st, (const _Float16*)s1, bs1, (const _Float16*)s2, bs2, map, (_Float16*)out, bso, n, C);
+    TCL_LAUNCH_RET();
+}
+int tcl_gather_rows_pair_f16(const void* sa, long bsa, const void* sb, long bsb, const int* map, void* oa, long boa, void* ob, long bob, int Bt, int n, int C,
+                             hipStream_t st) {
+    TCL_CHECK_ARG(sa && oa && (sb == nullptr) == (ob == nullptr) && Bt > 0 && n > 0 && C % 8 == 0);
+    int g = stream_grid((long)n * (C / 8), 256, 2); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_gather_rows_pair, dim3(g, Bt, sb ? 2 : 1), dim3(256), 0, st, (const _Float16*)sa, bsa, (const _Float16*)sb, bsb, map, (_Float16*)oa, boa,
+                       (_Float16*)ob, bob, n, C);
     TCL_LAUNCH_RET();
 }
 int tcl_gather_add_rows_f16(void* h, long bsh, const void* y, long bsy, const int* map, int Bt, int n, int C, hipStream_t st) {

@@ -74,6 +74,9 @@ class Generator:
                 free = 288 << 30
                 if torch.cuda.is_available() and self.dev.type == "cuda":      # the driver's free bytes + what this process's caching allocator holds unused
                     free = torch.cuda.mem_get_info(self.dev)[0] + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+                cap = self.unet.panel_cache_cap() if hasattr(self.unet, "panel_cache_cap") else 0     # persistent attention panels live beside the pass
+                cached = sum(a.numel() + b.numel() for a, b in getattr(self.unet, "_panel_cache", {}).values())
+                free -= max(0, cap - cached)
                 c.max_tokens_per_pass = int(min(16_000_000, max(1_000_000, 0.8 * free / 10_500)))
 
     # ------------------------------------------------------------------ data
@@ -237,9 +240,9 @@ class Generator:
         mode = "shard" if c.shard_post_opt else str(c.post_opt_mode)
         if mode not in ("replicated", "replicated_all", "global", "shard"):
             raise ValueError(f"post_opt_mode {mode!r}: expected replicated | replicated_all | global | shard")
-        shard = d.world > 1 and mode == "shard" and c.apply_opt
+        shard = d.multi and mode == "shard" and c.apply_opt
         lo, hi = d.range(self.n_total)
-        if d.world > 1 and not shard:
+        if d.multi and not shard:
             # decode slab by slab; every slab goes into an async all-gather while the next one decodes (parallel.gather_frames_pipelined)
             clean_local = None
             clean = d.gather_frames_pipelined(lambda a, b: self.vae.decode_latents_batch(x[a:b], self.batch_size), x.shape[0], self.n_total,
@@ -261,9 +264,9 @@ class Generator:
         losses1 = losses2 = None
         if c.apply_opt:
             N = clean.shape[0]
-            pd = d if (mode == "global" and d.world > 1) else None      # global: the ranks split every mini-batch and share one parameter set;
+            pd = d if (mode == "global" and d.multi) else None      # global: the ranks split every mini-batch and share one parameter set;
             #                                                           # replicated / shard: every rank optimises on its own (no collective)
-            pd1 = d if (mode in ("global", "replicated") and d.world > 1) else None      # stage 1: dealt over the ranks unless replicated_all / shard
+            pd1 = d if (mode in ("global", "replicated") and d.multi) else None      # stage 1: dealt over the ranks unless replicated_all / shard
             ds = post_opt.OptDataset(clean, past_flows, mask_bwds, device=self.dev)
             rng = np.random.default_rng(c.seed + (d.rank if shard else 0))      # global mode: the identical schedule on every rank
             s1 = post_opt.make_schedule(N, c.batch_size, c.epochs_exposure, rng)

@@ -26,8 +26,11 @@ from .hostlogic import shard_range
 
 
 class Dist:
-    def __init__(self, rank=0, world=1, timed=False):
+    def __init__(self, rank=0, world=1, timed=False, force_collectives=False):
         self.rank, self.world = rank, world
+        # force_collectives: issue every collective even at world == 1 (tests/test_gpu_rccl.py: the one GPU of a test box still runs each call through
+        # the RCCL backend -- communicator setup, the device-side kernels, stream ordering -- where the world == 1 shortcuts below would skip it)
+        self.multi = world > 1 or bool(force_collectives)
         # timed=True (bench.py, N > 1): every collective is bracketed by two EVENTS on the stream it is issued from -- resolved by
         # collect_stats() after the pass, so the timed region has no device-wide synchronise in it and compute / communication overlap as in an
         # un-instrumented run (rounds 3-4 synchronised the device on both sides of every call: ADVICE r4) -- and its bytes are counted.  The
@@ -70,7 +73,7 @@ class Dist:
 
     def gather_frames(self, x_local, n_total):
         """all-gather along dim 0 of uneven contiguous shards -> [n_total, ...]."""
-        if self.world == 1:
+        if not self.multi:
             return x_local
         nmax = -(-n_total // self.world)
         pad = torch.zeros((nmax,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
@@ -88,7 +91,7 @@ class Dist:
         latents).  Every slab is handed to an ASYNC all-gather as soon as it exists, so the transfer of slab s rides under the production of slab
         s + 1 (RCCL runs collectives on its own stream; the only exposed transfer is the last slab's).  Same result as
         gather_frames(produce(0, n_local), n_total)."""
-        if self.world == 1:
+        if not self.multi:
             return produce(0, n_local)
         if n_local < 1:
             raise ValueError(f"gather_frames_pipelined: rank {self.rank} holds no frame ({n_total} frames over {self.world} ranks): every rank needs at least one")
@@ -126,7 +129,7 @@ class Dist:
     def reduce_full(self, full):
         """Sum the per-rank partially filled full-size tensors (disjoint support) in place.  (Rounds 2-4's yt exchange; kept for A/B:
         TCL_YT_EXCHANGE=allreduce.)"""
-        if self.world > 1:
+        if self.multi:
             self._coll("all_reduce_yt_noise", full.numel() * full.element_size(), lambda: dist.all_reduce(full, op=dist.ReduceOp.SUM))
         return full
 
@@ -137,14 +140,14 @@ class Dist:
         return recv
 
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.multi:
             self._coll("all_reduce", t.numel() * t.element_size(), lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         return t
 
     def reduce_scatter_sum(self, full, out):
         """out[i] = sum over ranks of full[rank*len(out) + i]  (full.numel() == world * out.numel()).  RCCL: one reduce_scatter; gloo has
         no reduce_scatter, so the CPU tests take the all_reduce + slice route (same values)."""
-        if self.world == 1:
+        if not self.multi:
             out.copy_(full)
         elif dist.get_backend() == "nccl":
             self._coll("reduce_scatter", full.numel() * full.element_size(), lambda: dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM))
@@ -156,18 +159,18 @@ class Dist:
 
     def all_gather_into(self, full, shard):
         """full = concatenation over ranks of shard (equal sizes)."""
-        if self.world == 1:
+        if not self.multi:
             full.copy_(shard)
         else:
             self._coll("all_gather_rows", full.numel() * full.element_size(), lambda: dist.all_gather_into_tensor(full, shard))
         return full
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             dist.barrier()
 
     def max_float(self, v, device):
-        if self.world == 1:
+        if not self.multi:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,7 +209,7 @@ def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=N
         if it is not None:
             group.append(it)
     lo, hi = d.range(n_total)
-    if d.world == 1:
+    if not d.multi:
         return nt_full[lo:hi]
     if os.environ.get("TCL_YT_EXCHANGE", "allgather") == "allreduce":
         d.reduce_full(nt_full)
@@ -257,7 +260,7 @@ def distributed_adam_loop(d, sched, p_full, g_full, grad_fn, adam_fn, shard_stat
     new_zeros = new_zeros or (lambda n: torch.zeros(n, dtype=p_full.dtype, device=p_full.device))
     n = p_full.numel()
     losses = new_zeros(max(len(sched), 1))
-    if shard_state and d.world > 1:
+    if shard_state and d.multi:
         assert n % d.world == 0, "pad the flat parameter to a multiple of the world size"
         sz = n // d.world
         p = p_full[d.rank * sz:(d.rank + 1) * sz].clone()

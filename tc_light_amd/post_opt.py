@@ -184,7 +184,7 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
     expo = torch.eye(3, 4, device=dev)[None].repeat(n, 1, 1).contiguous()
     out = torch.empty_like(ed)
     L = lib()
-    if dist is None or dist.world == 1:
+    if dist is None or not dist.multi:
         g, m, v = (torch.zeros_like(expo) for _ in range(3))
         losses = torch.zeros(len(sched), device=dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)
@@ -248,7 +248,7 @@ def unique_tensor_optimization(dataset, unq_inv, batches, batch_size=16, feature
     L.tcl_scatter_mean_rgb2sh(ed, inv, feat, cnt, n, h, w, k, uniq, stream())
     del cnt
     out = torch.empty_like(ed)
-    if world == 1:
+    if dist is None or not dist.multi:
         g, m, v = (torch.zeros_like(feat) for _ in range(3))
         losses = torch.zeros(max(len(sched), 1), device=dev)
         ws = torch.empty(L.tcl_stage_workspace_bytes(batch_size, h, w), dtype=torch.uint8, device=dev)

@@ -289,6 +289,15 @@ class UNetEngine:
             cache[key] = torch.zeros(self.L.tcl_attention_q_bytes(B, Hh, Tq, d), dtype=torch.uint8, device=self.dev)
         return cache[key]
 
+    def panel_cache_cap(self):
+        """Byte bound of the persistent attention-panel cache: 8 % of the device's memory, at most 24 GiB (the 288 GB part: 23 GiB; ADVICE r5: the cap
+        was a constant the token budget of Generator.__init__ did not know about -- that budget now subtracts this figure from `free`)."""
+        cap = getattr(self, "_panel_cap", None)
+        if cap is None:
+            total = torch.cuda.get_device_properties(self.dev).total_memory if self.dev.type == "cuda" and torch.cuda.is_available() else (288 << 30)
+            cap = self._panel_cap = int(min(24 << 30, 0.08 * total))
+        return cap
+
     def _attn_panels(self, ne, Hh, T, d):
         """Zero-initialised Q and K / V^T panel workspaces per (entries, heads, merged length, head_dim), reused by every chunk and block that meets the shape
         again (all on the main stream: stream order serialises writer and readers).  tcl_gemm_qkv_panels_f16 never writes the panels' padding, which therefore
@@ -298,9 +307,14 @@ class UNetEngine:
         hit = cache.pop(key, None)
         if hit is None:
             nq, nkv = self.L.tcl_attention_q_bytes(ne, Hh, T, d), self.L.tcl_attention_kv_bytes(ne, Hh, T, d)
-            while cache and sum(a.numel() + b.numel() for a, b in cache.values()) + nq + nkv > (24 << 30):
+            while cache and sum(a.numel() + b.numel() for a, b in cache.values()) + nq + nkv > self.panel_cache_cap():
                 cache.pop(next(iter(cache)))                      # oldest first (dict order = insertion / last use)
-            hit = (torch.zeros(nq, dtype=torch.uint8, device=self.dev), torch.zeros(nkv, dtype=torch.uint8, device=self.dev))
+            try:
+                hit = (torch.zeros(nq, dtype=torch.uint8, device=self.dev), torch.zeros(nkv, dtype=torch.uint8, device=self.dev))
+            except torch.OutOfMemoryError:                        # a shared / smaller device: give the cached panels back and try once more
+                cache.clear()
+                torch.cuda.empty_cache()
+                hit = (torch.zeros(nq, dtype=torch.uint8, device=self.dev), torch.zeros(nkv, dtype=torch.uint8, device=self.dev))
         cache[key] = hit
         return hit
 
@@ -390,7 +404,8 @@ class UNetEngine:
                     main.wait_event(ev)
                     held = ((qkv,) + packed) if qkv_side else ((merged[0], merged[2]) if isinstance(merged, tuple) else (merged,))
                     for tns in held:                                               # allocated on the side stream's pool, read on the main stream
-                        tns.record_stream(main)
+                        if tns is not None:
+                            tns.record_stream(main)
                     if unm is not None:
                         unm.record_stream(main)
 

@@ -10,6 +10,7 @@ transformer block.  Differences, all deliberate and documented in DESIGN.md:
   * ties in the greedy matching are broken deterministically (csrc/merge.hip header).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -31,7 +32,10 @@ class VidToMe:
                          target_stride=target_stride, global_rand=global_rand)
         self.enabled = enabled
         self.rng = np.random.default_rng(seed)
-        self.banks = {}                 # block name -> [2, Tb, C] f16 (module.global_tokens, patch.py:60-82)
+        self.banks = {}                 # block name -> [2, Tb, C] f16 (module.global_tokens, patch.py:60-82); may be a strided view (see _home)
+        self._bank_met = {}             # block name -> the bank's cosine-normalised rows, same shape / strides (None: not carried, normalise on use)
+        self._home = {}                 # block name -> the [src | dst] blocks of the NEXT chunk, which already hold this bank in their slot (compute_merge)
+        self._cur = (None, 0)
         self._pos = {}
         self._ws = None
         self.draws = None               # optional injected (randf, coin) for the next forwards (parity tests); randf: int or one per round
@@ -41,6 +45,8 @@ class VidToMe:
     # ---- reference surface
     def reset_global_tokens(self):      # vidtome.update_patch(pipe, global_tokens=None)  (generate_utils.py:235-238)
         self.banks.clear()
+        self._bank_met.clear()
+        self._home.clear()
 
     def begin_forward(self, F, size):
         """One UNet forward over one chunk: fix the draws every patched block will see (lock-step generators of the reference)."""
@@ -76,7 +82,9 @@ class VidToMe:
 
     def select_chunk(self, i, chunks=None):
         """chunks: a list begin_step returned earlier (two groups of chunks in flight: unet.py forward_pair); default the last begin_step's."""
-        self.F, self.randfs, self.coin = (chunks if chunks is not None else self._chunks)[i]
+        lst = chunks if chunks is not None else self._chunks
+        self._cur = (lst, i)
+        self.F, self.randfs, self.coin = lst[i]
         self.randf = self.randfs[0] if self.randfs else -1
 
     def end_forward(self):
@@ -173,6 +181,110 @@ class VidToMe:
                 L.tcl_tome_match_f16(mt, mbs, Bt, C, a_pos, na, b_pos, nb, r, mo, uo, self._ws, stream())
         return mrg, unm, na - r + nb
 
+
+    # ---- round 6: the chain without `cat` and without a second normalisation
+    def _local_len(self, F, N):
+        """Tokens a single-round chunk of F frames keeps after the local merge (merge.py:90: r = min(na, int(na * ratio)))."""
+        if F <= 1:
+            return N
+        na = (F - 1) * N
+        return na - min(na, int(na * self.args["local_merge_ratio"])) + N
+
+    def _slots(self, coin, TL, Tb):
+        """(src_len, loff, boff) of the global match's [src | dst] block (patch.py:61-70)."""
+        return (TL, 0, TL) if coin > self.args["global_rand"] else (Tb, Tb, 0)
+
+    def _next_block(self, ne, TL_bank, N, C):
+        """If the chunk that will meet the bank this chunk leaves is known (the next one of the pass), allocate ITS [src | dst] token and metric blocks now
+        and return where the bank goes in them: (cat, catm, TL_next, loff, boff).  The bank is then written once, into place."""
+        lst, i = self._cur
+        if lst is None or i + 1 >= len(lst):
+            return None
+        Fn, _, coin_n = lst[i + 1]
+        if Fn > self.args["target_stride"]:
+            return None
+        TLn = self._local_len(Fn, N)
+        _, loff, boff = self._slots(coin_n, TLn, TL_bank)
+        T = TLn + TL_bank
+        return (torch.empty(ne, T, C, dtype=H16, device=self.dev), torch.empty(ne, T, C, dtype=H16, device=self.dev), TLn, loff, boff)
+
+    def _compute_merge_carried(self, name, x, F, N, C, xbs, metric, ne, lazy_merged):
+        """compute_merge for the shape every TC-Light configuration has (one local round, maps shared by the batch entries, global merge on), with the
+        cosine-normalised rows CARRIED beside the tokens instead of re-derived: normalisation is per row, so `normalise(gather(x))` == `gather(normalise(x))`
+        bit for bit, and the metric of the [local | bank] block is the two gathers the tokens take anyway (tcl_gather_rows_pair_f16: one launch moves
+        both).  The block itself is never copied together: the local survivors are gathered straight into their slot of it, and the bank was written into
+        its slot by the chunk that left it (`_next_block`: the next chunk's frame count and coin were drawn at begin_step, so its layout is known).
+        Per chunk and block this drops two copies of T x C, one normalisation of T x C (k_tome_normalize: 4.6 s of side-stream kernel time per 300-frame
+        pass in round 5) and three launches.  Same maps, tokens and banks as the legacy chain, bit for bit (tests/test_gpu_kernels.py, TCL_TOME_CAT=1)."""
+        a, L = self.args, self.L
+        FN, TL = F * N, self._local_len(F, N)
+        if metric is None:                                                      # norm1 did not write it (direct callers / TCL_LN_METRIC=0)
+            mx, mbs = torch.empty(ne, FN, C, dtype=H16, device=self.dev), FN * C
+            flat = x.reshape(-1)
+            for b in range(ne):
+                L.tcl_tome_normalize_f16(flat[b * xbs:], mx[b], FN, C, stream())
+        else:
+            mx, mbs = metric, xbs
+        mrg1 = unm1 = None
+        if F > 1:
+            a_pos, b_pos = self._positions(F, N, self.randf, 0)
+            mrg1, unm1, Tn = self._match(None, FN, C, a_pos, a_pos.numel(), b_pos, b_pos.numel(), a["local_merge_ratio"], tbs=mbs,
+                                         affine=(self.randf * N, N, self.randf * N), metric=mx, ne=ne)
+            assert Tn == TL
+        bank, bmet, home = self.banks.get(name), self._bank_met.get(name), self._home.pop(name, None)
+        if bank is None:                                                        # patch.py:81-82: the first chunk seeds the bank with its local tokens
+            nxt = self._next_block(ne, TL, N, C)
+            if nxt is not None:
+                cat_n, catm_n, TLn, loff_n, boff_n = nxt
+                tok, met = cat_n[:, boff_n:boff_n + TL], catm_n[:, boff_n:boff_n + TL]
+                self._home[name] = (cat_n, catm_n, TLn, loff_n, boff_n)
+            else:
+                tok, met = torch.empty(ne, TL, C, dtype=H16, device=self.dev), torch.empty(ne, TL, C, dtype=H16, device=self.dev)
+            L.tcl_gather_rows_pair_f16(x, xbs, mx, mbs, mrg1 if mrg1 is not None else 0, tok, tok.stride(0), met, met.stride(0), ne, TL, C, stream())
+            self.banks[name], self._bank_met[name] = tok, met
+            if self.trace is not None:
+                self.trace.append(dict(name=name, F=F, unm=unm1, gather=mrg1, mrg1=mrg1, T=TL))
+            merged = (tok, tok.stride(0), None) if lazy_merged else tok.contiguous()
+            return merged, unm1, TL
+        if bank.shape[0] != ne:
+            raise RuntimeError(f"VidToMe bank of block {name!r} was seeded with {bank.shape[0]} batch entr{'y' if bank.shape[0] == 1 else 'ies'}, this call "
+                               f"carries {ne}: call reset_global_tokens() when switching between forward_many(cfg_pair=True) and the two-entry paths")
+        Tb = bank.shape[1]
+        src_len, loff, boff = self._slots(self.coin, TL, Tb)
+        T = TL + Tb
+        if home is not None and home[0].shape == (ne, T, C) and home[2:] == (TL, loff, boff) and bank.data_ptr() == home[0][:, boff:].data_ptr():
+            cat, catm = home[0], home[1]                                        # the bank (and its metric) already sit in their slot
+        else:
+            cat, catm = torch.empty(ne, T, C, dtype=H16, device=self.dev), torch.empty(ne, T, C, dtype=H16, device=self.dev)
+            if bmet is not None:
+                L.tcl_gather_rows_pair_f16(bank, bank.stride(0), bmet, bmet.stride(0), 0, cat[:, boff:], T * C, catm[:, boff:], T * C, ne, Tb, C, stream())
+            else:
+                L.tcl_gather_rows_pair_f16(bank, bank.stride(0), 0, 0, 0, cat[:, boff:], T * C, 0, 0, ne, Tb, C, stream())
+                for b in range(ne):
+                    L.tcl_tome_normalize_f16(bank[b], catm[b, boff:], Tb, C, stream())
+        L.tcl_gather_rows_pair_f16(x, xbs, mx, mbs, mrg1 if mrg1 is not None else 0, cat[:, loff:], T * C, catm[:, loff:], T * C, ne, TL, C, stream())
+        mrg2, unm2, Tm = self._match(None, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len, a["global_merge_ratio"],
+                                     tbs=T * C, affine=(src_len, 0, src_len), metric=catm, ne=ne)
+        if lazy_merged:
+            merged = (cat, T * C, mrg2)
+        else:
+            merged = torch.empty(ne, Tm, C, dtype=H16, device=self.dev)
+            self._gather(cat, T * C, mrg2, merged, Tm * C, Tm, C, ne)
+        unm = self._compose(unm2, unm1, loff, FN)                               # 2s-unmerge then the randframe unmerge (func_warper(u_ls[::-1]))
+        bmap = self._compose(mrg2, unm2[loff:], 0, TL)                          # bank <- u(merged_tokens), local part (patch.py:80)
+        nxt = self._next_block(ne, TL, N, C)
+        if nxt is not None:
+            cat_n, catm_n, TLn, loff_n, boff_n = nxt
+            tok, met = cat_n[:, boff_n:boff_n + TL], catm_n[:, boff_n:boff_n + TL]
+            self._home[name] = (cat_n, catm_n, TLn, loff_n, boff_n)
+        else:
+            tok, met = torch.empty(ne, TL, C, dtype=H16, device=self.dev), torch.empty(ne, TL, C, dtype=H16, device=self.dev)
+        L.tcl_gather_rows_pair_f16(cat, T * C, catm, T * C, bmap, tok, tok.stride(0), met, met.stride(0), ne, TL, C, stream())
+        self.banks[name], self._bank_met[name] = tok, met
+        if self.trace is not None:
+            self.trace.append(dict(name=name, F=F, unm=unm, mrg2=mrg2, mrg1=mrg1, T=Tm, loff=loff, boff=boff, TL=TL, bmap=bmap))
+        return merged, unm, Tm
+
     # ---- patch.py:14-91
     def merges(self, N):
         """patch.py:15-18: does a block with N tokens per frame merge at all?"""
@@ -197,6 +309,10 @@ class VidToMe:
         L = self.L
         if xbs is None:
             xbs = F * N * C
+        if a["align_batch"] and a["merge_global"] and F <= a["target_stride"] and os.environ.get("TCL_TOME_CAT", "0") == "0":
+            return self._compute_merge_carried(name, x, F, N, C, xbs, metric, ne, lazy_merged)
+        self._home.pop(name, None)
+        self._bank_met.pop(name, None)
         # ---- local merging (patch.py:36-58): randframe rounds until one frame is left -- one round for F <= target_stride (every TC-Light
         # config), 8 -> 2 -> 1 / 16 -> 4 -> 1 for longer chunks, the unmerged tokens of a round riding along as extra dst tokens of the next
         mrg1 = unm1 = None
@@ -243,7 +359,7 @@ class VidToMe:
         T = TL + Tb
         cat = torch.empty(ne, T, C, dtype=H16, device=self.dev)
         L.tcl_gather_rows_f16(local, TL * C, 0, 0, 0, cat[:, loff:], T * C, ne, TL, C, stream())
-        L.tcl_gather_rows_f16(bank, Tb * C, 0, 0, 0, cat[:, boff:], T * C, ne, Tb, C, stream())
+        L.tcl_gather_rows_f16(bank, bank.stride(0), 0, 0, 0, cat[:, boff:], T * C, ne, Tb, C, stream())
         mrg2, unm2, Tm = self._match(cat, T, C, self._range(0, src_len), src_len, self._range(src_len, T), T - src_len,
                                      a["global_merge_ratio"], affine=(src_len, 0, src_len), ne=ne)
         if lazy_merged and mrg2.dim() == 1:

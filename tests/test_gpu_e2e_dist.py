@@ -97,13 +97,14 @@ def test_two_ranks_run_the_whole_pass():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
+    # the one-rank runs go through the GPU beside the two ranks (round 6: they used to wait for them -- launch-bound small kernels overlap well)
+    from tc_light_amd.parallel import Dist
+    one = {tag: _run(Dist(), on) for tag, on in (("A", False), ("B", True))}
+    other = _run(Dist(), True, tome_seed=777)     # a second one-rank run, same noise, other VidToMe draws (randf / src-dst coin): the scale of "another valid sample"
     two = ret.get()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    from tc_light_amd.parallel import Dist
-    one = {tag: _run(Dist(), on) for tag, on in (("A", False), ("B", True))}
-    other = _run(Dist(), True, tome_seed=777)     # a second one-rank run, same noise, other VidToMe draws (randf / src-dst coin): the scale of "another valid sample"
     # ---- A: the sharded choreography reproduces the one-rank run
     la, oa, l1a, l2a = two["A"]
     lr, orr, l1r, l2r = one["A"]

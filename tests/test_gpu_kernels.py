@@ -1,5 +1,7 @@
 """GPU: each path-1 HIP kernel (through the C ABI) against a plain PyTorch fp32 reference of the same op.
 Tolerance: inputs are f16, accumulation f32, outputs rounded to f16 -> rel-L2 <= 2e-3 per op."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -260,6 +262,58 @@ def test_vidtome_maps_vs_oracle(L):
             assert torch.equal(a, b)
             assert torch.equal((tome.banks["blk"].cpu().float() @ hv).sort(-1).values, (r["bank_new"] @ hv).sort(-1).values)   # same bank, as a set
         bank = tome.banks["blk"].cpu().float()       # continue the chain from the HIP bank so later rounds stay comparable
+
+
+def test_vidtome_carried_metric_chain_equals_legacy_chain(L):
+    """Round 6: compute_merge carries the cosine-normalised rows beside the tokens and writes local survivors / banks straight into the next
+    [src | dst] block (no `cat` copy, no second normalisation; vidtome.py `_compute_merge_carried`).  Every map, merged sequence and bank must equal
+    the legacy chain's (TCL_TOME_CAT=1: gather -> cat -> normalise -> match) BIT FOR BIT, over a multi-chunk pass in which the next chunk's layout is
+    planned ahead (begin_step with all chunks), with and without norm1's metric, with one and two batch entries, lazy and materialised merged
+    sequences, and across a pass boundary (a second begin_step meeting the bank the first one left)."""
+    from tc_light_amd.vidtome import VidToMe
+    g = np.random.default_rng(11)
+    N, C = 345, 320
+    passes = [[(4, 2, 0.9), (3, 0, 0.7), (4, 1, 0.1), (1, -1, 0.3), (2, 1, 0.8)], [(4, 3, 0.2), (4, 0, 0.6)]]
+    xs = [[torch.from_numpy(g.standard_normal((1, N, C)).astype(np.float32) + 0.3 * g.standard_normal((2 * F, N, C)).astype(np.float32)).half().cuda()
+           for F, _, _ in ps] for ps in passes]
+
+    def run(legacy, ne, with_metric, lazy):
+        os.environ["TCL_TOME_CAT"] = "1" if legacy else "0"
+        try:
+            tome = VidToMe("cuda")
+            tome.trace = []
+            outs = []
+            for ps, xp in zip(passes, xs):
+                tome.draws = [(rf, coin) for _, rf, coin in ps]
+                tome.begin_step([F for F, _, _ in ps], (15, 23))
+                for i, ((F, _, _), x) in enumerate(zip(ps, xp)):
+                    tome.select_chunk(i)
+                    xin = x[:F].contiguous() if ne == 1 else x
+                    met = None
+                    if with_metric:
+                        met = torch.empty_like(xin)
+                        L.tcl_tome_normalize_f16(xin, met, xin.shape[0] * N, C, st())
+                    merged, unm, T = tome.compute_merge("blk", xin, F, N, C, metric=met, ne=ne, lazy_merged=lazy)
+                    if isinstance(merged, tuple):
+                        src, sbs, idx = merged
+                        rows = torch.stack([torch.as_strided(src, (T if idx is None else src.shape[1], C), (C, 1), src.storage_offset() + b * sbs) for b in range(ne)])
+                        merged = rows if idx is None else rows[:, idx.long()]
+                    outs.append((merged.clone(), None if unm is None else unm.clone(), T, tome.banks["blk"].clone()))
+            torch.cuda.synchronize()
+            return outs, tome.trace
+        finally:
+            os.environ.pop("TCL_TOME_CAT", None)
+    for ne, with_metric, lazy in ((2, True, True), (2, False, False), (1, True, True), (2, True, False)):
+        (o_new, t_new), (o_old, t_old) = run(False, ne, with_metric, lazy), run(True, ne, with_metric, lazy)
+        assert len(o_new) == len(o_old) == 7
+        for k, ((m1, u1, T1, b1), (m0, u0, T0, b0)) in enumerate(zip(o_new, o_old)):
+            assert T1 == T0 and torch.equal(m1, m0) and torch.equal(b1, b0), (ne, with_metric, lazy, k)
+            assert (u1 is None and u0 is None) or torch.equal(u1, u0)
+        for a_, b_ in zip(t_new, t_old):
+            assert a_.keys() == b_.keys()
+            for key in a_:
+                va, vb = a_[key], b_[key]
+                assert (torch.equal(va, vb) if isinstance(va, torch.Tensor) else va == vb), key
 
 
 def _restored(merged, unm, F, N):

@@ -80,26 +80,80 @@ def synth_inputs(n, H, W, lo, hi, dev, seed=12345):
     return (d["frames"][lo:hi].to(dev), past, masks, ids.reshape(-1), k)
 
 
-def producer_timings(frames, dev):
-    """Stage-2 input producers that the reference runs inside its timed region (generate.py:595) but BASELINE's metric excludes: MemFlowNet
-    flow estimation (both directions, interleaved like video_dataparser.py:63-110, warm start off to keep the host-side scipy step out) and
-    BriaRMBG matting.  Seeded random weights; 8 frames of the workload."""
+def producer_timings(frames, dev, past_flows=None, masks=None):
+    """Stage-2 input producers that the reference runs inside its timed region (generate.py:595) but BASELINE's metric excludes: MemFlowNet flow
+    estimation (both directions, interleaved like video_dataparser.py:63-110, warm start off to keep the host-side scipy step out), BriaRMBG matting,
+    get_soft_mask_bwds + get_flowid (flow_utils.py:40-93) -- round 6 under the same discipline as the pass: wall clock per unit, the
+    FLOPs of the GEMM / implicit-conv calls (the library's launch profiler, counted in an eager pass: the product path replays HIP graphs) and the
+    fraction of the dense f16 MFMA peak they amount to over the WALL time of a unit; the id / mask producers against the HBM peak by their algorithmic
+    bytes.  Seeded random weights; 8 frames of the workload for the networks, the whole clip for the masks / ids.  Kernel tables: profiles/r6_memflow_kernel_stats.txt,
+    r6_rmbg_kernel_stats.txt (tools/micro/prof_producers.py under rocprofv3)."""
+    import ctypes
+    from tc_light_amd import flow_ids as FI
     from tc_light_amd import memflow as MF
     from tc_light_amd import rmbg as RM
+    from tc_light_amd.lib import lib
+    L = lib()
+
+    def counted(fn):
+        L.tcl_prof_begin(1)
+        fn()
+        torch.cuda.synchronize()
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        L.tcl_prof_end(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+        return ms.value, fl.value, cnt.value
+
+    def wall(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
     fr = frames[:8]
+    n = fr.shape[0]
+    out = {"note": "seeded random weights; never part of `value` (BASELINE's metric takes flows / masks as precomputed inputs)"}
     eng = MF.MemFlowEngine(MF.seeded_state_dict(MF.memflow_param_shapes(), 31), dev)
-    MF.estimate_flows(eng, fr[:2], warm_start=False)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    MF.estimate_flows(eng, fr, warm_start=False)
-    torch.cuda.synchronize(); t_flow = time.perf_counter() - t0
+    MF.estimate_flows(eng, fr[:4], warm_start=False)                       # shapes met once eagerly, then captured
+    t_flow = wall(lambda: MF.estimate_flows(eng, fr, warm_start=False))
+    os.environ["TCL_MEMFLOW_GRAPH"] = "0"
+    try:
+        t_eager = wall(lambda: MF.estimate_flows(eng, fr, warm_start=False))
+        ms, fl, cnt = counted(lambda: MF.estimate_flows(eng, fr, warm_start=False))
+    finally:
+        os.environ.pop("TCL_MEMFLOW_GRAPH", None)
+    pairs = 2 * (n - 1)
+    out.update(memflow_ms_per_frame_pair=t_flow / pairs * 1e3, memflow_pairs=pairs)
+    out["roofline_memflow"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "ms_per_pair": t_flow / pairs * 1e3,
+                               "ms_per_pair_eager_launches": t_eager / pairs * 1e3, "gemm_class_tflop_per_pair": fl / pairs / 1e12,
+                               "gemm_class_launches_per_pair": cnt / pairs, "gemm_class_event_ms_per_pair": ms / pairs,
+                               "achieved": fl / pairs / (t_flow / pairs) / 1e12, "frac": fl / t_flow / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                               "note": "15 GMA-SK2 iterations on a 90x160 grid: ~1 000 launches of 5-40 us per pair (M = 14 400 rows) -- launch-bound, not matrix-bound; "
+                                       "`achieved` = GEMM / conv FLOPs per pair / WALL time per pair (graph replay)"}
+    del eng
     rm = RM.RMBGEngine(RM.random_state_dict(1), dev)
     rm.estimate_alpha(fr[:2])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    rm.estimate_alpha(fr)
-    torch.cuda.synchronize(); t_rm = time.perf_counter() - t0
-    n = fr.shape[0]
-    return {"memflow_ms_per_frame_pair": t_flow / (2 * (n - 1)) * 1e3, "memflow_pairs": 2 * (n - 1), "rmbg_ms_per_frame": t_rm / n * 1e3,
-            "note": "MemFlowNet (15 iterations) and BriaRMBG engines on 8 frames of the workload, seeded random weights; not part of value"}
+    t_rm = wall(lambda: rm.estimate_alpha(fr))
+    ms, fl, cnt = counted(lambda: rm.estimate_alpha(fr))
+    out["rmbg_ms_per_frame"] = t_rm / n * 1e3
+    out["roofline_rmbg"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "ms_per_frame": t_rm / n * 1e3,
+                            "gemm_class_tflop_per_frame": fl / n / 1e12, "gemm_class_launches_per_frame": cnt / n, "gemm_class_event_ms_per_frame": ms / n,
+                            "achieved": fl / t_rm / 1e12, "frac": fl / t_rm / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS}
+    del rm
+    if past_flows is not None and masks is not None and past_flows.shape[0] == frames.shape[0]:
+        N, _, H, W = frames.shape
+        fwd = -past_flows.roll(-1, 0)
+        fwd[-1] = 0
+        FI.get_soft_mask_bwds(frames[:2], fwd[:2], past_flows[:2], alpha=0.5)
+        res = {}
+        t_m = wall(lambda: res.setdefault("m", FI.get_soft_mask_bwds(frames, fwd, past_flows, alpha=0.5)))
+        t_i = wall(lambda: res.setdefault("i", FI.get_flowid(frames, fwd, res["m"])))
+        P = H * W
+        # algorithmic bytes per pixel: masks = frame 12 + two flows 16 + the warped neighbour's taps (frame 12 + flow 8, once) + 4 written = 52; ids = frame and its
+        # predecessor 24 + flow 8 + mask 4 + predecessor's ids 4 + ids written 4 = 44
+        out["roofline_flow_ids"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "frames": N, "K": res["i"][1],
+                                    "soft_mask_ms": t_m * 1e3, "soft_mask_achieved": N * P * 52 / t_m / 1e9, "soft_mask_frac": N * P * 52 / t_m / 8e12,
+                                    "flowid_ms": t_i * 1e3, "flowid_achieved": N * P * 44 / t_i / 1e9, "flowid_frac": N * P * 44 / t_i / 8e12,
+                                    "note": "get_flowid is a sequential scan (frame i's ids need frame i-1's): one launch chain per frame"}
+    return out
 
 
 def _cpu_model():
@@ -279,7 +333,14 @@ def path2_traffic():
     if not fs:
         return None, None
     try:
-        return json.load(open(fs[-1]))["hbm_bytes_per_stage2_iteration"], os.path.basename(fs[-1])
+        j = json.load(open(fs[-1]))
+        # the counters must belong to the kernels that run (the traffic basis of round 5's line came from the build before its last path-2 change):
+        # the JSON carries the sha256 of csrc/path2.hip it was measured on; any other source -> no traffic basis, the line falls back to the effective rate
+        import hashlib
+        sha = hashlib.sha256(open(os.path.join(ROOT, "tc_light_amd", "csrc", "path2.hip"), "rb").read()).hexdigest()
+        if j.get("path2_hip_sha256") != sha:
+            return None, os.path.basename(fs[-1]) + " (STALE: measured on another csrc/path2.hip -- not used)"
+        return j["hbm_bytes_per_stage2_iteration"], os.path.basename(fs[-1])
     except Exception:
         return None, None
 
@@ -289,7 +350,11 @@ def path2_traffic_realistic():
     import glob
     fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_path2_traffic.json")))
     try:
-        return json.load(open(fs[-1]))["realistic_codebook_regime"]["hbm_bytes_per_stage2_iteration"], os.path.basename(fs[-1])
+        import hashlib
+        j = json.load(open(fs[-1]))
+        if j.get("path2_hip_sha256") != hashlib.sha256(open(os.path.join(ROOT, "tc_light_amd", "csrc", "path2.hip"), "rb").read()).hexdigest():
+            return None, os.path.basename(fs[-1]) + " (STALE: measured on another csrc/path2.hip -- not used)"
+        return j["realistic_codebook_regime"]["hbm_bytes_per_stage2_iteration"], os.path.basename(fs[-1])
     except Exception:
         return None, None
 
@@ -535,7 +600,8 @@ def main():
                                        f"ranks (14 KB all-reduce per iteration), stage 2 replicated on every rank (no collective; bit-reproducible); backend {backend}"
                                        + (" -- ranks SHARE GPUs (dry run of the N > 1 path, not a scaling measurement)" if ndev < world else ""))
                                       if world > 1 else "single GPU",
-                       "gemm_tile_table_entries_loaded": table_entries},
+                       "gemm_tile_table_entries_loaded": table_entries,
+                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None},
             "phase_seconds": {k: round(v, 3) for k, v in info["timing"].items()},
             "pass_seconds": dt / passes, "input_synthesis_seconds": round(t_setup, 1),
             "max_memory_allocated_MiB": round(info["max_memory_allocated"]),
@@ -545,6 +611,16 @@ def main():
                          "algorithmic_tflop_in_launches": fl / 1e12, "unet_algorithmic_tflop_per_pass": flops_pass / 1e12,
                          "unet_executed_tflop_per_pass": flops_exec / 1e12,
                          "cfg_pair_dedup": os.environ.get("TCL_CFG_DEDUP", "1") != "0", "how": prof_how,
+                         # north_star asks for >= 0.40 on this kernel: NOT met, and not reachable for head_dim 40 with this algorithm on this chip:
+                         "ceiling": {"north_star_target_frac": 0.40, "met": False,
+                                     "instruction_mix_floor_cycles_per_unit": 642, "unit": "32 queries x 64 keys of one head (327 680 algorithmic FLOP) per SIMD",
+                                     "floor_tflops_at_sustained_clock": 1024 * 327680 / 642 * 2.03e9 / 1e12, "sustained_clock_ghz_under_this_kernel": 2.03,
+                                     "floor_frac": 1024 * 327680 / 642 * 2.03e9 / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                                     "why": "one v_exp_f32 (8.3 issue cycles) and half a v_cvt_pk per score against 4 d = 160 FLOP of matrix work per score: tools/micro/flash_mix.hip "
+                                            "issues exactly the tile's instruction mix with independent operands and no LDS / DMA / barrier -> 642 cycles per unit at two waves per "
+                                            "SIMD; north_star's 0.40 needs < 560.  QK^T runs on K = 48 for 40 columns; the K = 8 MFMA forms that could trim it do not issue faster per "
+                                            "FLOP on gfx950 (profiles/r6_valu_rates.txt).  In the pass the kernel shares the CUs with the VidToMe matching chain: `frac` (in pass) "
+                                            "vs `alone.frac`"},
                          "basis": "event brackets: HIP events on the launch stream around each launch (the interval includes waiting for CUs held by co-running "
                                   "side-stream kernels); the kernel-time basis (rocprofv3 --kernel-trace of the same command) is profiles/r5_bench_kernel_stats.txt -- "
                                   "for this kernel the two agree to 1 %"},
@@ -631,7 +707,7 @@ def main():
             except Exception as e:
                 res.setdefault("roofline_path2", {})["realistic_codebook"] = {"error": repr(e)}
             try:                                               # the SURVEY 8(f) rows, measured beside the metric (never part of `value`)
-                res["producers"] = producer_timings(frames, dev)
+                res["producers"] = producer_timings(frames, dev, flows, masks)
             except Exception as e:
                 res["producers"] = {"error": repr(e)}
             del frames, flows, masks, inv

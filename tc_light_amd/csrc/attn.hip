@@ -608,7 +608,7 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
 }
 
 template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW, int NW>
-__global__ __launch_bounds__(64 * NW, (MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) * (NW / 4)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+__global__ __launch_bounds__(64 * NW, (MINB ? MINB : (QB == 1 && DP <= 80 && TPB == 1 ? 3 : 2)) * (NW >= 4 ? NW / 4 : 1)) void k_flash(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                                   _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
                                                   int kv_div, int nqb, int* __restrict__ flags, int nblk) {
     if constexpr (D == 40 && QB == 2 && !SPEC) {
@@ -1041,7 +1041,15 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (d == 80 && var80 == 8 && (long)B * H * (Tqp / 256) >= 256)
         return launch_flash<80, 80, 96, 1, 2, 1, 1, 0, 16, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 128) return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);   // MemFlowNet memory read
+    if (d == 128) {   // MemFlowNet memory read: ONE head, ONE entry -- at 1280x720 14 400 queries are 114 blocks of 128 for 256 CUs (profiles/r6_memflow_kernel_stats.txt:
+        // 507 us per call, 0.17 of peak).  Round 6: 2-wave blocks (64 queries) when the 4-wave grid leaves more than a third of the CUs idle -- same per-wave
+        // work and arithmetic (a wave's 32 queries see the same tiles in the same order: same bits), twice the blocks.  TCL_FLASH128_NW=4 keeps the old grid.
+        static const int nw128 = getenv("TCL_FLASH128_NW") ? atoi(getenv("TCL_FLASH128_NW")) : 0;
+        const long blocks4 = (long)B * H * (Tqp / 128);
+        if (nw128 == 2 || (nw128 == 0 && blocks4 < 170))
+            return launch_flash<128, 128, 128, 1, 2, 1, 0, 0, 16, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+        return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+    }
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
 }
 

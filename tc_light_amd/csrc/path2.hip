@@ -772,7 +772,10 @@ __global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __r
         if (raw & TL_SHARED) {                      // a track that other pixels of the clip share: claim it (one winner per launch)
             tl = TL_STEP(atomicMax(t_last + id, TL_SHARED | upto));
             if (tl >= upto) continue;
-        } else t_last[id] = upto;                   // a row only this pixel holds: nobody to race with, no atomic (98 % of the rows in the bench's regime)
+        } else {                                    // a row only this pixel holds: nobody to race with, no atomic (98 % of the rows in the bench's regime)
+            t_last[id] = upto;
+            if (tl == 0) continue;                  // ... and never stepped: m = v = 0, every skipped step is a no-op -- no row traffic at all (round 6)
+        }
         float pp[3], mm[3], vv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; }
@@ -783,9 +786,19 @@ __global__ void k_adam_catchup_frame(const int* __restrict__ inv, const int* __r
 }
 // rows of the cat rows blockIdx.y that stand at step - 1: apply `step` with their (complete) gradient, clear it.  One thread per row wins the
 // compare-and-swap of the step counter.
+// Round 6 -- RUN-AHEAD for unshared rows.  The mini-batch schedule of the whole stage is known on the host, so for every cat row of an iteration the NEXT
+// iteration that holds the same frame is known (`ahead.v[j]`: the step count the row must stand at when it is next gathered; the stage's last step if it
+// never returns).  A row that a single pixel holds is only ever visited through that frame: after its gradient step it is replayed (g = 0, the dense
+// kernel's instruction sequence, adam_elem) straight to that step while its p, m, v sit in registers, and t_last says so.  The catch-up launch of its next
+// visit then finds it up to date: 9 loads + 9 stores per row and visit less (2.6 GB of the 15 GB an iteration moved), the replay arithmetic is done once
+// as before, now under this kernel's own memory traffic instead of in a launch of its own.  Shared rows (TL_SHARED: several pixels, possibly of frames
+// with different schedules) keep the visit-time catch-up.  Same bits as the dense schedule (test_stage2_lazy_adam_equals_dense).
+struct AheadArg { int v[128]; };
 __global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __restrict__ fidx, int P, size_t K, int* __restrict__ t_last,
                                      float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int step, float lr,
-                                     float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                                     float b1, float b2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ bc1_tab,
+                                     const float* __restrict__ bc2_tab, AheadArg ahead) {
+    const int upto_next = ahead.v[blockIdx.y];      // >= step; == step: no run-ahead (TCL_ADAM_RUNAHEAD=0)
     // a frame can sit in the cat list twice (as a current frame and as the previous frame of another slot): only its FIRST occurrence walks its pixels --
     // with the unshared rows no longer claimed by an atomic, two blocks on the same pixel would both step its row
     for (int q = 0; q < (int)blockIdx.y; ++q) if (fidx[q] == fidx[blockIdx.y]) return;
@@ -794,15 +807,18 @@ __global__ void k_adam_touched_frame(const int* __restrict__ inv, const int* __r
         const size_t id = (size_t)iv[px];
         const int raw = t_last[id];
         if (TL_STEP(raw) != step - 1) continue;
-        if (raw & TL_SHARED) {
+        const bool shared = raw & TL_SHARED;
+        if (shared) {
             if (atomicCAS(t_last + id, TL_SHARED | (step - 1), TL_SHARED | step) != (TL_SHARED | (step - 1))) continue;      // stepped by another frame of this mini-batch
-        } else t_last[id] = step;                   // unshared row: no claim needed
+        } else t_last[id] = upto_next;              // unshared row: no claim needed; it leaves this kernel at the step of its next visit
+        float pp[3], mm[3], vv[3], gg[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float pi = p[c * K + id], mi = m[c * K + id], vi = v[c * K + id];
-            adam_elem(pi, mi, vi, g[c * K + id], lr, b1, b2, eps, bc1, bc2_sqrt);
-            p[c * K + id] = pi; m[c * K + id] = mi; v[c * K + id] = vi; g[c * K + id] = 0.f;
-        }
+        for (int c = 0; c < 3; ++c) { pp[c] = p[c * K + id]; mm[c] = m[c * K + id]; vv[c] = v[c * K + id]; gg[c] = g[c * K + id]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) adam_elem(pp[c], mm[c], vv[c], gg[c], lr, b1, b2, eps, bc1, bc2_sqrt);
+        if (!shared && upto_next > step) adam_replay(pp, mm, vv, step + 1, upto_next, lr, b1, b2, eps, bc1_tab, bc2_tab);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c * K + id] = pp[c]; m[c * K + id] = mm[c]; v[c * K + id] = vv[c]; g[c * K + id] = 0.f; }
     }
 }
 // ---- round 5: ONE visit per row and iteration with a write.  The catch-up launch is gone: the gather replays a row's skipped steps in REGISTERS
@@ -1206,6 +1222,25 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
         } else if (hipMemsetD32Async((hipDeviceptr_t)t_last, TL_SHARED, K, st) != hipSuccess) return TCL_ELAUNCH;      // a clip of >= 2^31 pixels: the pixel numbers of the marking pass do not fit an int -- every row claimed with an atomic, as before
         if (upload_table(bc1, tab.data(), tab.size(), st) != TCL_OK) return TCL_ELAUNCH;
     }
+    // run-ahead table (see k_adam_touched_frame): ahead[it][j] = the next iteration whose cat list ([cur | max(cur - 1, 0)], post_opt._pack_schedule) holds
+    // the frame of cat row j of iteration `it`, or `iters`.  One backward sweep over the schedule.
+    static const bool runahead = !(getenv("TCL_ADAM_RUNAHEAD") && atoi(getenv("TCL_ADAM_RUNAHEAD")) == 0);
+    std::vector<int> ahead_tab;
+    if (lazy) {
+        ahead_tab.assign((size_t)iters * 2 * batch, 0);
+        std::vector<int> nxt((size_t)N, iters);
+        for (int it = iters - 1; it >= 0; --it) {
+            const int* bi = sched + (size_t)it * batch;
+            int b = 0;
+            while (b < batch && bi[b] >= 0) ++b;
+            for (int j = 0; j < 2 * b; ++j) {
+                const int f = j < b ? bi[j] : (bi[j - b] > 0 ? bi[j - b] - 1 : 0);
+                TCL_CHECK_ARG(f >= 0 && f < N);
+                ahead_tab[(size_t)it * 2 * batch + j] = runahead ? nxt[f] : it + 1;
+            }
+            for (int j = 0; j < 2 * b; ++j) nxt[j < b ? bi[j] : (bi[j - b] > 0 ? bi[j - b] - 1 : 0)] = it;
+        }
+    }
     for (int it = 0; it < iters; ++it) {
         const int* bi = sched + (size_t)it * batch;
         int b = 0, nvalid = 0;
@@ -1230,8 +1265,10 @@ int tcl_unique_tensor_opt(const float* target, const float* flows, const float* 
                                0.999f, 1e-15f, bc1, bc2);
         } else if (lazy) {
             const float c1 = (float)(1.0 - pow((double)0.9f, it + 1)), c2 = (float)sqrt(1.0 - pow((double)0.999f, it + 1));
+            AheadArg ah;
+            for (int j = 0; j < 2 * b; ++j) ah.v[j] = ahead_tab[(size_t)it * 2 * batch + j];
             hipLaunchKernelGGL(k_adam_touched_frame, pgrid(P, 2 * b), dim3(256), 0, st, unq_inv, cidx, (int)P, K, t_last, feat, g, m, v, it + 1, lr, 0.9f,
-                               0.999f, 1e-15f, c1, c2);
+                               0.999f, 1e-15f, c1, c2, bc1, bc2, ah);
         } else {
             rc = tcl_adam_step(feat, g, m, v, K * 3, lr, 0.9f, 0.999f, 1e-15f, it + 1, st);
             if (rc) return rc;

@@ -10,6 +10,7 @@ but never builds the all-pairs volume: windows are computed on demand from an av
 Pinned against the reference modules by tests/golden/memflow_*.npz (tests/test_gpu_memflow.py).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -347,9 +348,60 @@ class MemFlowEngine:
 
     @torch.no_grad()
     def step(self, images, end=False, flow_init=None):
-        """InferenceCore.step: images [1,2,3,H,W] f32 in [-1,1] (H, W multiples of 8; H/8/8 >= 2) -> (flow_low [1,2,H/8,W/8], flow_up [1,2,H,W])."""
+        """InferenceCore.step: images [1,2,3,H,W] f32 in [-1,1] (H, W multiples of 8; H/8/8 >= 2) -> (flow_low [1,2,H/8,W/8], flow_up [1,2,H,W]).
+
+        Round 6: a frame pair is ~1 050 launches of kernels that take 5-40 us each (P = 14 400 rows at 1280x720) -- the host could not issue them as fast as
+        the GPU retires them (45.7 ms per pair in round 5's bench line against the kernel time in profiles/r6_memflow_kernel_stats.txt).  The device work of
+        a step is therefore captured ONCE per (image shape, memory length, warm start or not) into a HIP graph and replayed: the first step of a shape runs
+        eagerly (it also lets the GEMM tile table meet the shapes), the second one is captured, every later one is copy-in -> one graph launch -> copy-out.
+        Same kernels, same order, same arguments: same bits (tests/test_gpu_memflow.py runs both).  TCL_MEMFLOW_GRAPH=0 keeps every step eager."""
+        d = self.dev
+        images = images.to(d).float().contiguous()
+        fi = None if flow_init is None else flow_init.to(d).float().contiguous()
+        Tm = 0 if self.mem_k is None else self.mem_k.shape[0]
+        use = os.environ.get("TCL_MEMFLOW_GRAPH", "1") != "0" and d.type == "cuda"
+        if use:
+            key = (tuple(images.shape), Tm, fi is not None)
+            graphs = self.__dict__.setdefault("_graphs", {})
+            ent = graphs.get(key)
+            if ent is None:
+                graphs[key] = "seen"                                 # eager this time
+                ent = None
+            elif ent == "seen":
+                ent = graphs[key] = self._capture(images, fi, Tm)
+            if isinstance(ent, dict):
+                ent["images"].copy_(images)
+                if fi is not None:
+                    ent["fi"].copy_(fi)
+                if Tm:
+                    ent["mk"].copy_(self.mem_k); ent["mv"].copy_(self.mem_v)
+                ent["graph"].replay()
+                flow_low, up, k_all, v_all = (t.clone() for t in ent["out"])
+                self._remember(k_all, v_all, end, Tm)
+                return flow_low, up
+        flow_low, up, k_all, v_all = self._core(images, self.mem_k, self.mem_v, fi)
+        self._remember(k_all, v_all, end, Tm)
+        return flow_low, up
+
+    def _remember(self, k_all, v_all, end, Tm):
+        if not end:                                                # mem_every = 1 (inference_core_skflow.py:25, :49-51)
+            self.mem_k, self.mem_v = k_all, v_all
+            P = k_all.shape[0] - Tm
+            if self.mem_k.shape[0] >= self.max_mt * P:             # compress_features: keep the last min_mt frames
+                self.mem_k, self.mem_v = self.mem_k[-self.min_mt * P:].contiguous(), self.mem_v[-self.min_mt * P:].contiguous()
+
+    def _capture(self, images, fi, Tm):
+        ent = dict(images=images.clone(), fi=None if fi is None else fi.clone(), mk=self.mem_k.clone() if Tm else None, mv=self.mem_v.clone() if Tm else None)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ent["out"] = self._core(ent["images"], ent["mk"], ent["mv"], ent["fi"])
+        ent["graph"] = g
+        return ent
+
+    def _core(self, images, mem_k, mem_v, flow_init):
+        """The device work of one step: (images, working memory, warm start) -> (flow_low, flow_up, k_all, v_all)."""
         L, d = self.L, self.dev
-        images = images.to(d).float()
         # context: net = tanh(c[:, :128]), inp = relu(c[:, 128:]), (query, key) = to_qk(inp)   (MemFlow.py:112-118)
         c, (h, w) = self.cnet.forward(images[:, 0])
         P = h * w
@@ -362,9 +414,9 @@ class MemFlowEngine:
         corr_fn = CorrBlock.from_nhwc(fm[0:1].contiguous(), fm[1:2].contiguous())
         ys, xs = torch.meshgrid(torch.arange(h, device=d).float(), torch.arange(w, device=d).float(), indexing="ij")
         coords0 = torch.stack([xs, ys])[None].contiguous()
-        coords1 = coords0.clone() if flow_init is None else (coords0 + flow_init.to(d).float()).contiguous()
+        coords1 = coords0.clone() if flow_init is None else (coords0 + flow_init).contiguous()
         corr_rows = torch.zeros(P, 384, dtype=H16, device=d)       # 324 channels + zero padding
-        k_all = key if self.mem_k is None else torch.cat([self.mem_k, key])
+        k_all = key if mem_k is None else torch.cat([mem_k, key])
         T = k_all.shape[0]
         scale = self.scale * np.log(T) / np.log(self.tal)          # memory_manager_skflow.py:59 (math.log(T, train_avg_length))
         wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P, 128), dtype=torch.uint8, device=d)
@@ -379,7 +431,7 @@ class MemFlowEngine:
             mf = self._pc(self.conv, self._cat(cor, flo, P), 1, h, w)          # [P,128]: 126 channels + 2 zero
             L.tcl_nchw_f32_to_rows_f16(flow, mf, 1, 2, P, 128, 126, 0, stream())  # torch.cat([out, flow], 1)   (sk2.py:128)
             val = self._gemm(mf, self.to_v, P)
-            v_all = val if self.mem_v is None else torch.cat([self.mem_v, val])
+            v_all = val if mem_v is None else torch.cat([mem_v, val])
             ro = torch.empty(P, 128, dtype=H16, device=d)
             L.tcl_attention_f16(qk, 256, P * 256, k_all, 128, T * 128, v_all, 128, T * 128, ro, 128, P * 128, 1, 1, P, T, 128, float(scale), 1, 1, wq, wkv,
                                 stream())
@@ -394,11 +446,7 @@ class MemFlowEngine:
         flow_low = coords1 - coords0
         up = torch.empty(1, 2, 8 * h, 8 * w, dtype=torch.float32, device=d)
         L.tcl_upsample_flow_f32(flow_low.contiguous(), mask, 576, 0.25, up, 1, h, w, stream())
-        if not end:                                                # mem_every = 1 (inference_core_skflow.py:25, :49-51)
-            self.mem_k, self.mem_v = k_all, v_all
-            if self.mem_k.shape[0] >= self.max_mt * P:             # compress_features: keep the last min_mt frames
-                self.mem_k, self.mem_v = self.mem_k[-self.min_mt * P:].contiguous(), self.mem_v[-self.min_mt * P:].contiguous()
-        return flow_low, up
+        return flow_low, up, k_all, v_all
 
 
 # ------------------------------------------------------------------------------------------------ video-level driver

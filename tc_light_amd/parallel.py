@@ -165,6 +165,22 @@ class Dist:
             self._coll("all_gather_rows", full.numel() * full.element_size(), lambda: dist.all_gather_into_tensor(full, shard))
         return full
 
+    def same_bits_or_broadcast(self, t, what="tensor"):
+        """All ranks should hold the same bits of `t` (a replicated parameter after an all-reduced update).  Checks it with one small all-reduce (MAX of
+        [c, -c], c = a 53-bit checksum of the bit pattern held in an f64) and, on a mismatch, warns and broadcasts rank 0's copy."""
+        if not self.multi:
+            return True
+        v = t.detach().contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+        c = ((v * (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1)).sum() % (1 << 52)).to(torch.float64)
+        pair = torch.stack([c, -c])
+        dist.all_reduce(pair, op=dist.ReduceOp.MAX)
+        same = bool((pair[0] == -pair[1]).item())
+        if not same:
+            import warnings
+            warnings.warn(f"{what}: the ranks' copies differ after the all-reduced update (backend {dist.get_backend()}): taking rank 0's")
+            dist.broadcast(t, src=0)
+        return same
+
     def barrier(self):
         if self.multi:
             dist.barrier()

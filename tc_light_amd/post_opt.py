@@ -210,6 +210,10 @@ def exposure_align(dataset, batches, epochs, batch_size=16, lr_init=0.01, lr_fin
             L.tcl_adam_step(p, gg, m, v, p.numel(), lr, 0.9, 0.999, 1e-8, it + 1, stream())
 
         losses = distributed_adam_loop(dist, sched, expo.view(-1), g, grad_fn, adam_fn, shard_state=False)
+        # Stage 2 runs REPLICATED behind this (generate.py default): every rank must hold the same exposure bits -- true when the backend's all-reduce hands
+        # every rank the same sum (RCCL ring / tree do), silently false otherwise.  One 16-byte exchange says which: the ranks' bit-pattern
+        # checksums must agree (max == min).  A mismatch is healed by taking rank 0's parameters, loudly.
+        dist.same_bits_or_broadcast(expo, "stage-1 exposure")
         L.tcl_apply_exposure(ed, 0, expo, out, n, h, w, stream())
     dataset.edited_images = out
     return out, expo, losses

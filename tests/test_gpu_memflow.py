@@ -109,3 +109,30 @@ def test_estimate_flows_vs_oracle_driver(dev):
                 low_o, up_o = core.step(pair, flow_init=None if prev[is_future] is None else prev[is_future].cpu())
                 assert ((up.cpu() - up_o).norm() / up_o.norm()).item() < 1.5e-2, (idx, is_future)
                 prev[is_future] = MF.forward_interpolate(low[0])[None].to(dev)
+
+
+def test_step_graph_replay_equals_eager(dev, monkeypatch):
+    """Round 6: MemFlowEngine.step replays a captured HIP graph from the third step of a shape on (first eager, second captured).  Ten frame pairs through one
+    working memory with warm starts, graphs on against TCL_MEMFLOW_GRAPH=0: every flow bit-identical, and the graph path really replayed (>= 6 replays)."""
+    from tc_light_amd import memflow as MF
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "memflow_full.npz"))
+    sd = MF.seeded_state_dict(MF.memflow_param_shapes(), int(G["seed"]))
+    frames = torch.from_numpy(G["frames"]).to(dev)
+    n = frames.shape[0]
+
+    def run(graph):
+        monkeypatch.setenv("TCL_MEMFLOW_GRAPH", "1" if graph else "0")
+        eng, outs, init = MF.MemFlowEngine(sd, dev), [], None
+        for i in range(10):
+            a, b = frames[i % n], frames[(i * 3 + 1) % n]
+            low, up = eng.step(torch.stack([a, b])[None], flow_init=init)
+            outs.append((low.clone(), up.clone()))
+            init = (0.5 * low).contiguous()                                    # a device-side warm start (the driver's scipy one is host work)
+        torch.cuda.synchronize()
+        return outs, eng
+    o1, e1 = run(True)
+    o0, _ = run(False)
+    for i, ((l1, u1), (l0, u0)) in enumerate(zip(o1, o0)):
+        assert torch.equal(l1, l0) and torch.equal(u1, u0), i
+    replayed = [v for v in e1._graphs.values() if isinstance(v, dict)]
+    assert len(replayed) >= 1 and len(e1._graphs) <= 3, e1._graphs.keys()

@@ -31,10 +31,18 @@ CASES = [
 ]
 
 
+PINNED_HIP = "7.2."        # the run lengths below were measured on this compiler (ROCm 7.2.0, AMD clang 22.0.0git): a perf lint, not a correctness test --
+#                          # another scheduler may legitimately issue the loads differently, so other versions skip unless TCL_ISA_LINT=1 insists
+
+
 @pytest.fixture(scope="module")
 def asm():
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
+    ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    m = re.search(r"HIP version:\s*(\S+)", ver)
+    if not (m and m.group(1).startswith(PINNED_HIP)) and os.environ.get("TCL_ISA_LINT", "0") != "1":
+        pytest.skip(f"ISA lint is pinned to hipcc {PINNED_HIP}x (found {m.group(1) if m else 'unknown'}); TCL_ISA_LINT=1 runs it anyway")
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         procs = {}

@@ -75,6 +75,17 @@ def _worker(rank, world, port, n_total, ret):
     if rank == 0:
         ret.put(full.numpy())            # numpy, not torch tensors: fd-shared tensors need the producer alive until the parent unpickles
     assert d.max_float(float(rank), "cpu") == world - 1
+    # replicated parameters after an all-reduced update: same bits on every rank is checked, a mismatch is healed from rank 0 (round 6)
+    import warnings
+    e = torch.linspace(-1, 1, 36).view(3, 3, 4).clone()
+    assert d.same_bits_or_broadcast(e, "exposure") is True
+    e2 = e.clone()
+    if rank == world - 1:
+        e2[1, 2, 3] = torch.nextafter(e2[1, 2, 3], torch.tensor(2.0))           # one ulp on one rank
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        assert d.same_bits_or_broadcast(e2, "exposure") is False
+    assert len(wlist) == 1 and torch.equal(e2, e)
     dist.destroy_process_group()
 
 

@@ -7,7 +7,7 @@ R=${1:-r4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-IT=6
+IT=${2:-38}      # two epochs of the 300-frame clip (19 iterations each): the second epoch's visits are re-visits (lazy Adam: run-ahead rows, round 6)
 for reuse in 0.02 0.7; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pq_${c}_$reuse
@@ -45,7 +45,9 @@ for reuse, key in (("0.02", "bench_codebook_regime"), ("0.7", "realistic_codeboo
     out[key] = {"hbm_bytes_per_stage2_iteration": tot, "one_off_bytes_per_stage": once, "iterations_per_call": it,
                 "microbench_line_under_counters": line[-1].strip() if line else None, "per_kernel": per_kernel}
 out["hbm_bytes_per_stage2_iteration"] = out["bench_codebook_regime"]["hbm_bytes_per_stage2_iteration"]
-out["how"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/micro/bench_p2.py 300 720 1280 6 <reuse>, stage 2 only; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every kernel of the process / iterations"
+import hashlib, os
+out["path2_hip_sha256"] = hashlib.sha256(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "tc_light_amd", "csrc", "path2.hip"), "rb").read()).hexdigest()      # bench.py reports the traffic basis only for THIS source
+out["how"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/micro/bench_p2.py 300 720 1280 <iterations_per_call> <reuse>, stage 2 only; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over every kernel of the process / iterations"
 print(json.dumps(out, indent=1))
 PY
 head -c 1500 $OUT/path2_traffic.json

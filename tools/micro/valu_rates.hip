@@ -6,6 +6,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define REP8(X) X X X X X X X X
 #define REP64(X) REP8(REP8(X))
 template <int OP>
@@ -29,6 +30,10 @@ __global__ void k(unsigned long long* out, float seed) {
                                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, accb, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, accb, 0, 0, 0); } }
         if (OP == 8) { for (int i = 0; i < 8; ++i) { acc4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4, 0, 0, 0); acc4b = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4b, 0, 0, 0); acc4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4, 0, 0, 0); acc4b = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4b, 0, 0, 0);
                                             acc4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4, 0, 0, 0); acc4b = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4b, 0, 0, 0); acc4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4, 0, 0, 0); acc4b = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv, hv, acc4b, 0, 0, 0); } }
+        // round 6: the K = 8 / K = 16 forms of CDNA3, still in the gfx950 ISA: does a 32x32x8 issue in HALF the cycles of 32x32x16?  If so QK^T at
+        // head_dim 40 could run as 2 x K=16 + 1 x K=8 (40 columns) instead of 3 x K=16 (48: 17 % of its matrix cycles are padding)
+        if (OP == 10) { half4 h4 = {1, 2, 3, 4}; for (int i = 0; i < 32; ++i) { acc = __builtin_amdgcn_mfma_f32_32x32x8f16(h4, h4, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_32x32x8f16(h4, h4, accb, 0, 0, 0); } }
+        if (OP == 11) { half4 h4 = {1, 2, 3, 4}; for (int i = 0; i < 32; ++i) { acc4 = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, h4, acc4, 0, 0, 0); acc4b = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, h4, acc4b, 0, 0, 0); } }
         if (OP == 9) {   // the flash mix per MFMA: 32x32x16 MFMA + 4 exp + 2 cvt, all independent
             for (int i = 0; i < 8; ++i) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hv, hv, acc, 0, 0, 0);
@@ -56,5 +61,6 @@ int main() {
     run<0>("v_exp_f32", 64, d); run<1>("v_mul_f32", 64, d); run<2>("v_cvt_pk_f16_f32", 64, d); run<3>("v_permlane16_swap_b32", 64, d);
     run<4>("v_or3_b32", 64, d); run<5>("v_max3_f32", 64, d); run<6>("v_pk_mul_f32", 64, d);
     run<7>("mfma_32x32x16_f16", 64, d); run<8>("mfma_16x16x32_f16", 64, d); run<9>("mix: mfma32 + 4 exp + 2 cvt", 8 * 2, d);
+    run<10>("mfma_32x32x8_f16", 64, d); run<11>("mfma_16x16x16_f16", 64, d);
     return 0;
 }

@@ -300,6 +300,13 @@ int tcl_corr_lookup_rows_f16(const float* fmap1, const float* const* fmap2_level
                              const float* coords, void* out_rows, int ld, int B, int H, int W, int D, int radius, hipStream_t st);
 int tcl_corr_lookup_f32(const float* fmap1, const float* const* fmap2_levels, const int* level_h, const int* level_w, int num_levels,
                         const float* coords, float* out, int B, int H, int W, int D, int radius, int out_nchw, hipStream_t st);
+/* tcl_corr_lookup_rows_f16 for ONE entry and radius 4 with the neighbour rows shared by 8 x 8 pixel tiles (round 6; the windows of a tile's pixels overlap
+ * almost completely under a smooth flow): fmap1_h / fmap2_levels_h = the same maps in f16 (level 0 is the encoder's f16 output itself, the pooled levels are
+ * rounded once); a tile whose windows span more than 512 points is computed by the per-pixel f32 kernel from fmap1 / fmap2_levels instead (same call).
+ * tile_flags: num_levels * ceil(H/8) * ceil(W/8) ints of scratch, rewritten by every call (1 = that tile took the per-pixel route). */
+int tcl_corr_lookup_rows_tiled_f16(const void* fmap1_h, const void* const* fmap2_levels_h, const float* fmap1, const float* const* fmap2_levels,
+                                   const int* level_h, const int* level_w, int num_levels, const float* coords, void* out_rows, int ld, int H, int W, int D,
+                                   int radius, int* tile_flags, hipStream_t st);
 
 /* ---- BriaRMBG-1.4 matting (briarmbg.py, generate.py:147-167).  f32 NCHW.
  * tcl_conv3x3_direct_f32: Conv2d(k=3, padding=dilation, dilation, stride 1|2) over x = cat([x1, x2], channel) (x2 may be NULL, C2 = 0)

@@ -1041,12 +1041,12 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
     if (d == 80 && var80 == 8 && (long)B * H * (Tqp / 256) >= 256)
         return launch_flash<80, 80, 96, 1, 2, 1, 1, 0, 16, 8>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     if (d == 80) return launch_flash<80, 80, 96, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
-    if (d == 128) {   // MemFlowNet memory read: ONE head, ONE entry -- at 1280x720 14 400 queries are 114 blocks of 128 for 256 CUs (profiles/r6_memflow_kernel_stats.txt:
-        // 507 us per call, 0.17 of peak).  Round 6: 2-wave blocks (64 queries) when the 4-wave grid leaves more than a third of the CUs idle -- same per-wave
-        // work and arithmetic (a wave's 32 queries see the same tiles in the same order: same bits), twice the blocks.  TCL_FLASH128_NW=4 keeps the old grid.
-        static const int nw128 = getenv("TCL_FLASH128_NW") ? atoi(getenv("TCL_FLASH128_NW")) : 0;
-        const long blocks4 = (long)B * H * (Tqp / 128);
-        if (nw128 == 2 || (nw128 == 0 && blocks4 < 170))
+    if (d == 128) {   // MemFlowNet memory read: ONE head, ONE entry -- at 1280x720 14 400 queries are 114 blocks of 128 for 256 CUs (profiles/r6_memflow_kernel_stats_before.txt:
+        // 507 us per call, 0.17 of peak).  Round 6 tried 2-wave blocks (64 queries, twice the blocks; same per-wave work and bits): the frame pair got SLOWER, 47.7
+        // against 45.9 ms on one box (profiles/r6_ab_memflow_graph_nw.txt) -- a 2-wave block issues twice the LDS-DMA pieces per wave and hides less of it; the
+        // kernel is not simply grid-limited.  TCL_FLASH128_NW=2 selects that form; 4 waves stay the default.
+        static const int nw128 = getenv("TCL_FLASH128_NW") ? atoi(getenv("TCL_FLASH128_NW")) : 4;
+        if (nw128 == 2)
             return launch_flash<128, 128, 128, 1, 2, 1, 0, 0, 16, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
         return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     }

@@ -23,12 +23,19 @@ struct CorrLevels { const float* f2[4]; int H[4], W[4]; };
 // out[b][(l*n + a)*n + b2] at pixel (y,x): x offset a - r, y offset b2 - r (the reference's meshgrid(dy, dx) order), * 1/sqrt(D)
 template <typename OT>
 __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f1, CorrLevels lv, const float* __restrict__ coords, OT* __restrict__ out,
-                                                     int B, int H, int W, int D, int r, long out_cs, long out_ps, long out_bs, float inv_sqrt_d) {
+                                                     int B, int H, int W, int D, int r, long out_cs, long out_ps, long out_bs, float inv_sqrt_d,
+                                                     const int* __restrict__ tile_flags = nullptr) {
     __shared__ float part[4][32][65];
     __shared__ float dots[4][144];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, l = blockIdx.y, b = blockIdx.z;
     const int pix = blockIdx.x * 4 + wid, P = H * W;
-    const bool live = pix < P;
+    bool live = pix < P;
+    if (tile_flags) {      // round 6: the pass behind k_corr_lookup_tile -- only the pixels of the 8x8 tiles that kernel gave up on (wave-uniform: a wave is one pixel)
+        const int tx = (W + 7) >> 3, ty = (H + 7) >> 3;
+        const int pc = pix < P ? pix : P - 1;
+        if (!tile_flags[l * tx * ty + ((pc / W) >> 3) * tx + ((pc % W) >> 3)]) live = false;
+        // (the four waves of a block may disagree; every wave still takes part in nothing block-wide below: part[wid] / dots[wid] are per wave)
+    }
     const int n1 = 2 * r + 2, npts = n1 * n1, n = 2 * r + 1;            // r <= 5 -> npts <= 144
     const int Hl = lv.H[l], Wl = lv.W[l];
     const float* g = lv.f2[l] + (long)b * Hl * Wl * D;
@@ -82,6 +89,116 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
     }
 }
 
+
+// ---- round 6: the lookup with the neighbour rows SHARED by a tile of pixels.
+// k_corr_lookup streams 100 rows of 1 KiB per (pixel, level) out of L2 -- 5.9 GB per call at 1280x720 / 8, 660 us, 26 % of a MemFlowNet frame pair
+// (profiles/r6_memflow_kernel_stats_before.txt).  The windows of neighbouring pixels overlap almost completely when the flow is smooth: a tile of 8 x 8 pixels
+// needs the rows of ONE bounding box of ~(8 / 2^l + 10)^2 points.  A block therefore stages that box, 32 features at a time, in LDS (f16: level 0 is
+// the encoder's f16 output as it stands, the pooled levels are rounded once), and every thread takes a quarter of one pixel's 100 window points:
+// 25 dot products per thread on v_dot2_f32_f16 with f32 accumulation in a fixed order (deterministic), the bilinear mix of corr.py:95-112 last, same formula and
+// order as k_corr_lookup.  166 KB instead of 6.5 MB of L2 reads per tile and level.  A tile whose box exceeds CRMAX points (a flow that tears the tile
+// apart) raises its flag and is left to k_corr_lookup, launched behind with the flags as a filter.
+#define CT_K 32            // features per LDS slice
+#define CT_STR 40          // LDS row stride in halves: 80 B = 5 x 16 B, odd -> 16-byte reads of 64 different rows are conflict-free
+#define CT_RMAX 512        // box points a block stages (22 x 23); one more all-zero row stands in for points outside the image / the box
+struct CorrLevelsH { const _Float16* f2[4]; int H[4], W[4]; };
+typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ch2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256, 2) void k_corr_lookup_tile(const _Float16* __restrict__ f1, CorrLevelsH lv, const float* __restrict__ coords,
+                                                             _Float16* __restrict__ out, int H, int W, int D, long ld, float inv_sqrt_d,
+                                                             int* __restrict__ tile_flags) {
+    constexpr int R = 4, N1 = 2 * R + 2, NP = N1 * N1, N = 2 * R + 1, PT = NP / 4;          // 100 window points, 25 per thread
+    __shared__ __attribute__((aligned(16))) _Float16 reg[(CT_RMAX + 1) * CT_STR];
+    __shared__ float dots[64][NP + 1];
+    __shared__ int s_x0[64], s_y0[64], s_box[4];
+    __shared__ float s_fx[64], s_fy[64];
+    const int tid = threadIdx.x, pixl = tid & 63, part = tid >> 6, l = blockIdx.y;
+    const int tx = (W + 7) >> 3, tile = blockIdx.x, P = H * W;
+    const int py = (tile / tx) * 8 + (pixl >> 3), px = (tile % tx) * 8 + (pixl & 7);
+    const bool live = py < H && px < W;
+    const int pix = live ? py * W + px : 0;
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const _Float16* __restrict__ g = lv.f2[l];
+    if (tid < 64) {
+        float cx = 0.f, cy = 0.f;
+        if (live) { const float sc = 1.f / (float)(1 << l); cx = coords[pix] * sc; cy = coords[P + pix] * sc; }
+        const float x0f = floorf(cx), y0f = floorf(cy);
+        // (a coordinate far outside the image must not overflow the int conversion: clamp, the window is outside either way)
+        const int x0 = (int)fminf(fmaxf(x0f, -1e6f), 1e6f) - R, y0 = (int)fminf(fmaxf(y0f, -1e6f), 1e6f) - R;
+        s_x0[tid] = x0; s_y0[tid] = y0; s_fx[tid] = cx - x0f; s_fy[tid] = cy - y0f;
+        int mnx = live ? x0 : 0x3fffffff, mxx = live ? x0 + N1 - 1 : -0x3fffffff, mny = live ? y0 : 0x3fffffff, mxy = live ? y0 + N1 - 1 : -0x3fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
+            mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+        }
+        if (tid == 0) {
+            mnx = max(mnx, 0); mny = max(mny, 0); mxx = min(mxx, Wl - 1); mxy = min(mxy, Hl - 1);
+            s_box[0] = mnx; s_box[1] = mny; s_box[2] = mxx - mnx + 1; s_box[3] = mxy - mny + 1;
+        }
+    }
+    for (int i = tid; i < CT_STR; i += 256) reg[CT_RMAX * CT_STR + i] = (_Float16)0.f;       // the zero row
+    __syncthreads();
+    const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
+    const bool empty = bw <= 0 || bh <= 0;
+    const long nreg_l = empty ? 0 : (long)bw * bh;
+    if (nreg_l > CT_RMAX) { if (tid == 0) tile_flags[l * gridDim.x + tile] = 1; return; }      // block-uniform: left to k_corr_lookup
+    if (tid == 0) tile_flags[l * gridDim.x + tile] = 0;
+    const int nreg = (int)nreg_l;
+    // this thread's 25 window points -> LDS row offsets (halves); outside the image (= outside the clipped box): the zero row
+    int off[PT];
+    {
+        const int x0 = s_x0[pixl], y0 = s_y0[pixl];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int p = part * PT + j, ry = y0 + p / N1 - by0, rx = x0 + p % N1 - bx0;
+            off[j] = (live && !empty && ry >= 0 && ry < bh && rx >= 0 && rx < bw) ? (ry * bw + rx) * CT_STR : CT_RMAX * CT_STR;
+        }
+    }
+    float acc[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) acc[j] = 0.f;
+    const _Float16* __restrict__ q = f1 + (long)pix * D;
+    for (int ks = 0; ks < D; ks += CT_K) {
+        __syncthreads();                                  // the previous slice has been read by everybody
+        for (int i = tid >> 2; i < nreg; i += 64) {      // 4 threads per row: 4 x 16 B = the row's 32 features of this slice
+            const int iy = by0 + i / bw, ix = bx0 + i % bw;
+            *(ch8*)(reg + i * CT_STR + (tid & 3) * 8) = *(const ch8*)(g + ((long)iy * Wl + ix) * D + ks + (tid & 3) * 8);
+        }
+        ch8 qv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qv[c] = *(const ch8*)(q + ks + c * 8);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const _Float16* row = reg + off[j];
+            float a = acc[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const ch8 v = *(const ch8*)(row + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const ch2 a2 = {qv[c][2 * e], qv[c][2 * e + 1]}, b2 = {v[2 * e], v[2 * e + 1]};
+                    a = __builtin_amdgcn_fdot2(a2, b2, a, false);
+                }
+            }
+            acc[j] = a;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j) dots[pixl][part * PT + j] = acc[j];
+    __syncthreads();
+    if (!live) return;
+    const float fx = s_fx[pixl], fy = s_fy[pixl];
+    _Float16* o = out + (long)pix * ld + (long)l * N * N;
+    for (int idx = part; idx < N * N; idx += 4) {
+        const int a = idx / N, b2 = idx % N;                              // a: x offset, b2: y offset (the reference's meshgrid(dy, dx) order)
+        const float* d0 = &dots[pixl][b2 * N1 + a];
+        const float v = (1.f - fx) * (1.f - fy) * d0[0] + fx * (1.f - fy) * d0[1] + (1.f - fx) * fy * d0[N1] + fx * fy * d0[N1 + 1];
+        o[idx] = (_Float16)(v * inv_sqrt_d);
+    }
+}
+
 extern "C" {
 
 int tcl_avgpool2_nhwc_f32(const float* x, float* y, int B, int H, int W, int D, hipStream_t st) {
@@ -117,6 +234,30 @@ int tcl_corr_lookup_rows_f16(const float* fmap1, const float* const* fmap2_level
     for (int i = 0; i < num_levels; ++i) TCL_CHECK_ARG(lv.f2[i] && lv.H[i] > 0 && lv.W[i] > 0);
     hipLaunchKernelGGL(k_corr_lookup<_Float16>, dim3(cdiv(P, 4), num_levels, B), dim3(256), 0, st, fmap1, lv, coords, (_Float16*)out_rows, B, H, W, D, radius,
                        (long)1, (long)ld, (long)P * ld, 1.f / sqrtf((float)D));
+    TCL_LAUNCH_RET();
+}
+
+// round 6: the same rows from the tile-sharing kernel (f16 feature maps; one entry, radius 4, D % 32 == 0), then k_corr_lookup over the pixels of the tiles that
+// kernel flagged (box > CT_RMAX points).  tile_flags: num_levels * ceil(H/8) * ceil(W/8) ints of scratch (written by every call).
+int tcl_corr_lookup_rows_tiled_f16(const void* fmap1_h, const void* const* fmap2_levels_h, const float* fmap1, const float* const* fmap2_levels,
+                                   const int* level_h, const int* level_w, int num_levels, const float* coords, void* out_rows, int ld, int H, int W, int D,
+                                   int radius, int* tile_flags, hipStream_t st) {
+    TCL_CHECK_ARG(fmap1_h && fmap2_levels_h && fmap1 && fmap2_levels && level_h && level_w && coords && out_rows && tile_flags && H > 0 && W > 0);
+    TCL_CHECK_ARG(num_levels >= 1 && num_levels <= 4 && radius == 4 && D % 64 == 0 && D <= 512);
+    const int n = 2 * radius + 1, P = H * W, C = num_levels * n * n;
+    TCL_CHECK_ARG(ld >= C);
+    CorrLevels lv; CorrLevelsH lh;
+    for (int i = 0; i < 4; ++i) {
+        lv.f2[i] = i < num_levels ? fmap2_levels[i] : nullptr; lh.f2[i] = i < num_levels ? (const _Float16*)fmap2_levels_h[i] : nullptr;
+        lv.H[i] = lh.H[i] = i < num_levels ? level_h[i] : 0; lv.W[i] = lh.W[i] = i < num_levels ? level_w[i] : 0;
+    }
+    for (int i = 0; i < num_levels; ++i) TCL_CHECK_ARG(lv.f2[i] && lh.f2[i] && lv.H[i] > 0 && lv.W[i] > 0);
+    const int tiles = ((H + 7) / 8) * ((W + 7) / 8);
+    const float isd = 1.f / sqrtf((float)D);
+    hipLaunchKernelGGL(k_corr_lookup_tile, dim3(tiles, num_levels), dim3(256), 0, st, (const _Float16*)fmap1_h, lh, coords, (_Float16*)out_rows, H, W, D, (long)ld, isd,
+                       tile_flags);
+    hipLaunchKernelGGL(k_corr_lookup<_Float16>, dim3(cdiv(P, 4), num_levels, 1), dim3(256), 0, st, fmap1, lv, coords, (_Float16*)out_rows, 1, H, W, D, radius,
+                       (long)1, (long)ld, (long)P * ld, isd, (const int*)tile_flags);
     TCL_LAUNCH_RET();
 }
 
@@ -275,6 +416,12 @@ int tcl_subsample2_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, 
 // y = gelu(x + depthwise_kxk(x) + bias)  (sk2.py:26-27: `x = F.gelu(x + conv(x))`); x, y [B,H,W,C] f16 NHWC, w [k*k][C] f16, k odd.
 // Block = 16x16 output pixels x 8 channels: the (16+k-1)^2 input halo of those 8 channels is staged in LDS once (16 B per pixel), every
 // thread then reads its k*k taps from LDS; the 8-channel weight vectors are block-uniform (scalar loads).
+// acc += f16(lo | hi half of v2) * f16(lo | hi half of w2), one instruction: v_fma_mix_f32 converts the halves exactly and rounds once -- the same value as
+// cvt, cvt, fma (an f16 x f16 product is exact in f32), at a third of the issue slots.  hipcc does not select it here (it emits 256 v_cvt + 96 fma / pk_fma per
+// kernel row of 15 taps, round 6 ISA reading): the 15x15 depthwise convolutions were 18 % of a MemFlowNet frame pair.
+__device__ __forceinline__ void fma_mix_lo(float& acc, unsigned v2, unsigned w2) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(v2), "s"(w2)); }
+__device__ __forceinline__ void fma_mix_hi(float& acc, unsigned v2, unsigned w2) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(v2), "s"(w2)); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int K>
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
                                                      _Float16* __restrict__ y, int H, int W, int C) {
@@ -301,10 +448,14 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const _Float16* __restrict_
     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-            const h8 v = tile[(ly + ky) * TS + lx + kx];
-            const h8 wv = *(const h8*)(w + (long)(ky * K + kx) * C + ch);        // block-uniform
+            const u32x4 v = *(const u32x4*)&tile[(ly + ky) * TS + lx + kx];
+            const u32x4 wl = *(const u32x4*)(w + (long)(ky * K + kx) * C + ch);   // block-uniform: scalar loads
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * (float)wv[j];
+            for (int j = 0; j < 4; ++j) {
+                const unsigned ws_ = __builtin_amdgcn_readfirstlane(wl[j]);
+                fma_mix_lo(acc[2 * j], v[j], ws_);
+                fma_mix_hi(acc[2 * j + 1], v[j], ws_);
+            }
         }
     const h8 xc = tile[(ly + R) * TS + lx + R];
     h8 o;

@@ -243,6 +243,11 @@ class CorrBlock:
             L.tcl_avgpool2_nhwc_f32(lv[-1], nxt, B, hs[-1], ws[-1], D, stream())
             lv.append(nxt); hs.append(h); ws.append(w)
         self.levels = lv
+        # round 6: f16 copies for the tile-sharing lookup (tcl_corr_lookup_rows_tiled_f16): level 0 came out of the encoder in f16, so this is its exact value;
+        # the pooled levels are rounded once (f32 pooling chain above, as before)
+        self.f1h, self.levels_h = self.f1.half(), [t.half() for t in lv]
+        self._ptrs_h = (ctypes.c_void_p * num_levels)(*[t.data_ptr() for t in self.levels_h])
+        self._flags = torch.zeros(num_levels * ((H + 7) // 8) * ((W + 7) // 8), dtype=torch.int32, device=fmap1.device)
         self._ptrs = (ctypes.c_void_p * num_levels)(*[t.data_ptr() for t in lv])
         self._hs = (ctypes.c_int * num_levels)(*hs)
         self._ws = (ctypes.c_int * num_levels)(*ws)
@@ -255,6 +260,10 @@ class CorrBlock:
     def lookup_rows(self, coords, out_rows):
         """Window lookup written as f16 rows [B*H*W, ld] (first L*(2r+1)^2 channels) for the motion encoder's GEMM."""
         B, D, H, W = self.shape
+        if B == 1 and self.radius == 4 and os.environ.get("TCL_CORR_TILED", "1") != "0":
+            lib().tcl_corr_lookup_rows_tiled_f16(self.f1h, self._ptrs_h, self.f1, self._ptrs, self._hs, self._ws, self.num_levels, coords, out_rows,
+                                                 out_rows.shape[1], H, W, D, self.radius, self._flags, stream())
+            return
         lib().tcl_corr_lookup_rows_f16(self.f1, self._ptrs, self._hs, self._ws, self.num_levels, coords, out_rows, out_rows.shape[1], B, H, W, D,
                                        self.radius, stream())
 
@@ -350,16 +359,18 @@ class MemFlowEngine:
     def step(self, images, end=False, flow_init=None):
         """InferenceCore.step: images [1,2,3,H,W] f32 in [-1,1] (H, W multiples of 8; H/8/8 >= 2) -> (flow_low [1,2,H/8,W/8], flow_up [1,2,H,W]).
 
-        Round 6: a frame pair is ~1 050 launches of kernels that take 5-40 us each (P = 14 400 rows at 1280x720) -- the host could not issue them as fast as
-        the GPU retires them (45.7 ms per pair in round 5's bench line against the kernel time in profiles/r6_memflow_kernel_stats.txt).  The device work of
-        a step is therefore captured ONCE per (image shape, memory length, warm start or not) into a HIP graph and replayed: the first step of a shape runs
-        eagerly (it also lets the GEMM tile table meet the shapes), the second one is captured, every later one is copy-in -> one graph launch -> copy-out.
-        Same kernels, same order, same arguments: same bits (tests/test_gpu_memflow.py runs both).  TCL_MEMFLOW_GRAPH=0 keeps every step eager."""
+        Round 6, measured and OFF by default: a frame pair is ~1 050 launches of kernels that take 5-40 us each (P = 14 400 rows at 1280x720), which looked
+        launch-bound -- it is not: the kernel table (profiles/r6_memflow_kernel_stats_before.txt) sums to 48.4 ms per pair against 50.4 ms of wall clock; the
+        host keeps ahead of the GPU.  With TCL_MEMFLOW_GRAPH=1 the device work of a step is captured ONCE per (image shape, memory length, warm start or not)
+        into a HIP graph and replayed (first step of a shape eager, second captured, later ones copy-in -> one graph launch -> copy-out; same kernels, order
+        and arguments: same bits, tests/test_gpu_memflow.py::test_step_graph_replay_equals_eager) -- 48.2-48.9 ms per pair against 47.7 eager on one box
+        (profiles/r6_ab_memflow_graph_nw.txt): the copies cost what the launch gaps saved.  What a pair spends is kernel time: correlation lookup 26 %, memory-read
+        attention 20 %, 15x15 depthwise convolutions 18 %, small GEMMs 21 %."""
         d = self.dev
         images = images.to(d).float().contiguous()
         fi = None if flow_init is None else flow_init.to(d).float().contiguous()
         Tm = 0 if self.mem_k is None else self.mem_k.shape[0]
-        use = os.environ.get("TCL_MEMFLOW_GRAPH", "1") != "0" and d.type == "cuda"
+        use = os.environ.get("TCL_MEMFLOW_GRAPH", "0") == "1" and d.type == "cuda"
         if use:
             key = (tuple(images.shape), Tm, fi is not None)
             graphs = self.__dict__.setdefault("_graphs", {})

@@ -112,7 +112,7 @@ def test_estimate_flows_vs_oracle_driver(dev):
 
 
 def test_step_graph_replay_equals_eager(dev, monkeypatch):
-    """Round 6: MemFlowEngine.step replays a captured HIP graph from the third step of a shape on (first eager, second captured).  Ten frame pairs through one
+    """Round 6: with TCL_MEMFLOW_GRAPH=1 MemFlowEngine.step replays a captured HIP graph from the third step of a shape on (first eager, second captured).  Ten frame pairs through one
     working memory with warm starts, graphs on against TCL_MEMFLOW_GRAPH=0: every flow bit-identical, and the graph path really replayed (>= 6 replays)."""
     from tc_light_amd import memflow as MF
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "memflow_full.npz"))
@@ -121,7 +121,7 @@ def test_step_graph_replay_equals_eager(dev, monkeypatch):
     n = frames.shape[0]
 
     def run(graph):
-        monkeypatch.setenv("TCL_MEMFLOW_GRAPH", "1" if graph else "0")
+        monkeypatch.setenv("TCL_MEMFLOW_GRAPH", "1" if graph else "0")             # (opt-in: measured no faster, profiles/r6_ab_memflow_graph_nw.txt)
         eng, outs, init = MF.MemFlowEngine(sd, dev), [], None
         for i in range(10):
             a, b = frames[i % n], frames[(i * 3 + 1) % n]
@@ -136,3 +136,51 @@ def test_step_graph_replay_equals_eager(dev, monkeypatch):
         assert torch.equal(l1, l0) and torch.equal(u1, u0), i
     replayed = [v for v in e1._graphs.values() if isinstance(v, dict)]
     assert len(replayed) >= 1 and len(e1._graphs) <= 3, e1._graphs.keys()
+
+
+def test_corr_lookup_tiled_rows_vs_per_pixel_kernel(dev, monkeypatch):
+    """Round 6: lookup_rows through the tile-sharing kernel (f16 feature maps, 8 x 8 pixel tiles share one bounding box of neighbour rows in LDS) against the
+    per-pixel f32 kernel on the SAME f16-representable features (the encoder's outputs are f16): (a) a smooth flow -- every tile compact, no fallback; (b) the
+    same plus a few torn tiles and windows hanging over every image border -- those tiles take the per-pixel route inside the same call; (c) a flow that tears
+    every tile apart -- all fallback, bit-identical to the per-pixel kernel.  H, W no multiples of 8 (partial tiles).  Levels 1-3 are f16-rounded in the tiled
+    kernel: tolerance 2e-3 of the correlation scale."""
+    from tc_light_amd.memflow import CorrBlock
+    g = torch.Generator().manual_seed(5)
+    B, D, H, W = 1, 256, 45, 83
+    f1 = torch.randn(B, D, H, W, generator=g).half().float().to(dev)
+    f2 = torch.randn(B, D, H, W, generator=g).half().float().to(dev)
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    base = torch.stack([xs, ys])[None]
+    smooth = base + torch.stack([2.3 + 1.5 * torch.sin(xs / 30 + ys / 50), -1.2 + 1.0 * torch.cos(ys / 25)])[None]
+    torn = smooth.clone()
+    torn[:, :, 8:16, 16:24] += 40 * torch.randn(1, 2, 8, 8, generator=g)               # one torn tile
+    torn[:, 0, :, :3] -= 7.5; torn[:, 0, :, -3:] += 9.25; torn[:, 1, :2] -= 6.0; torn[:, 1, -2:] += 8.5        # windows over the borders
+    wild = base + 60 * torch.randn(1, 2, H, W, generator=g)
+    cb = CorrBlock(f1, f2)
+    n_tiles = cb._flags.numel()
+    for name, co, want_fb in (("smooth", smooth, 0), ("torn", torn, None), ("wild", wild, "most")):
+        co = co.to(dev).contiguous()
+        rows_t = torch.zeros(H * W, 384, dtype=torch.float16, device=dev)
+        rows_p = torch.zeros_like(rows_t)
+        monkeypatch.setenv("TCL_CORR_TILED", "1")
+        cb.lookup_rows(co, rows_t)
+        fb = int(cb._flags.sum().item())
+        monkeypatch.setenv("TCL_CORR_TILED", "0")
+        cb.lookup_rows(co, rows_p)
+        torch.cuda.synchronize()
+        a, b = rows_t.float().cpu(), rows_p.float().cpu()
+        assert torch.equal(a[:, 324:], b[:, 324:])                                     # padding channels untouched
+        err = (a - b).abs().max().item()
+        print(f"[corr tiled, {name}] fallback tiles {fb} / {n_tiles} (4 levels), max |diff| {err:.2e} of scale {b.abs().max().item():.2f}")
+        assert err < 2e-3 * max(1.0, b.abs().max().item()), (name, err)
+        if want_fb == 0:
+            assert fb == 0
+        elif want_fb == "most":
+            assert fb > n_tiles // 4
+            lv0 = cb._flags[:n_tiles // 4].bool().cpu()                                 # level 0: every pixel of a flagged tile comes from the f32 kernel -> same bits
+            tx = (W + 7) // 8
+            tile_of = ((ys.long() // 8) * tx + xs.long() // 8).reshape(-1)
+            m = lv0[tile_of]
+            assert m.any() and torch.equal(a[m][:, :81], b[m][:, :81])
+        else:
+            assert 0 < fb < n_tiles // 2

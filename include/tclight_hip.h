@@ -287,6 +287,13 @@ int tcl_flash_profile_shape(int* shape4);        /* (B, H, Tq, Tk) of the larges
 int tcl_prof_begin(int mask);
 int tcl_prof_end(int cls, double* total_ms, double* total_work, long* launches);
 
+/* Split-KV attention for ONE entry, head_dim 128 (round 6: the MemFlowNet memory read, memory_manager_skflow.py:44-69 -- one head, 14 400 queries at 1280x720
+ * are 114 blocks for 256 CUs).  The keys are cut into nsplit chunks that run as batch entries of the flash kernel; each writes its normalised partial output and
+ * log2 of its softmax denominator, a merge kernel joins them.  q [Tq, ldq], k [Tk, ldk], v [Tk, ldv] (head h at column h*d), o [Tq, ldo]; Tk % (64 nsplit) == 0. */
+size_t tcl_attention_splitkv_workspace_bytes(int nsplit, int H, int Tq, int Tk, int d);
+int tcl_attention_splitkv_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int H, int Tq, int Tk, int d,
+                              float scale, int nsplit, void* ws, hipStream_t st);
+
 /* ---- MemFlowNet correlation lookup (utils/evaluation/memflow/core/Networks/MemFlowNet/corr.py:74-120 CorrBlock,
  * computed on demand like the reference's unused alt_cuda_corr extension -- the all-pairs volume never exists).  f32, NHWC feature maps.
  * tcl_avgpool2_nhwc_f32: F.avg_pool2d(2, 2) (floor on odd sizes) -- builds the fmap2 pyramid level by level.

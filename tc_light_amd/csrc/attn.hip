@@ -134,10 +134,10 @@ __device__ __forceinline__ float xhalf_max(float v) {
 
 // (the body of k_flash for ONE block index: the kernel below calls it once, or -- the flag-gated exact pass behind the speculative kernel -- once per
 // flagged index of its stride class)
-template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW, int NW>
+template <int D, int DP, int DPV, int QB, int NSTG, int TPB, int MINB, int SPEC, int PVW, int NW, bool SPLIT = false>
 __device__ __forceinline__ void flash_block(const int bid, const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
                                             _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride,
-                                            int kv_div, int nqb, int* __restrict__ flags) {
+                                            int kv_div, int nqb, int* __restrict__ flags, float* __restrict__ lse = nullptr) {
     constexpr int KS = DP + 8;                    // K row stride (halves); KS/8 odd -> conflict-free b128 reads
     constexpr int NQK = DP / 16, NDT = DPV / 32;
     constexpr int KBYTES = KV_TILE * KS * 2, VBYTES = vt_tile_halves(DPV) * 2, SBYTES = KBYTES + VBYTES;
@@ -591,6 +591,9 @@ __device__ __forceinline__ void flash_block(const int bid, const _Float16* __res
         }
         const float inv = 1.f / l;
         const int q = q0 + qb * 32 + ql;
+        if constexpr (SPLIT) {      // split-KV (k_flash_lse): this entry saw one chunk of the keys -- hand on log2 of its softmax denominator at the shift it used
+            if (q < Tq && hl == 0) lse[bh * Tq + q] = m[qb] + __log2f(l);
+        }
         if (q < Tq) {
             _Float16* orow = O + (long)b * obstride + (long)q * ldo + head * d;
 #pragma unroll
@@ -888,6 +891,39 @@ static int launch_flash(const _Float16* Qp, const _Float16* Kp, const _Float16* 
     return hipPeekAtLastError() == hipSuccess ? TCL_OK : TCL_ELAUNCH;
 }
 
+// ---- round 6: split-KV for the MemFlowNet memory read (head_dim 128, ONE head, ONE entry: 14 400 queries are 114 blocks for 256 CUs -- 512 us per call,
+// 0.17 of peak, a quarter of a frame pair).  The keys are cut into `nsplit` chunks that ride as batch entries (the Q panel is packed once per chunk, the
+// K / V^T panels of a chunk are a batch entry's), every entry writes its normalised partial output and log2 of its denominator, and k_attn_merge joins them:
+// O = sum_s 2^(lse_s - max) O_s / sum_s 2^(lse_s - max).  Same kernel body as k_flash<128, ...> (flash_block with SPLIT).
+template <int D, int DP, int DPV, int QB, int NSTG>
+__global__ __launch_bounds__(256, 2) void k_flash_lse(const _Float16* __restrict__ Qp, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vt,
+                                                      _Float16* __restrict__ O, int H, int Tq, int Tk, int Tqp, int Tkp, int d, int ldo, long obstride, int nqb,
+                                                      float* __restrict__ lse) {
+    flash_block<D, DP, DPV, QB, NSTG, 1, 0, 0, 16, 4, true>(blockIdx.x, Qp, Kp, Vt, O, H, Tq, Tk, Tqp, Tkp, d, ldo, obstride, 1, nqb, nullptr, lse);
+}
+// parts [S][Tq][HD] f16, lse [S][H][Tq] -> out [Tq][ldo] (first HD columns)
+__global__ void k_attn_merge(const _Float16* __restrict__ parts, const float* __restrict__ lse, _Float16* __restrict__ out, int S, int H, int Tq, int d, int ldo) {
+    const int HD = H * d, nchunk = HD / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)Tq * nchunk; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i / nchunk), c8 = (int)(i % nchunk) * 8, h = c8 / d;
+        float mx = -3.0e38f;
+        for (int sidx = 0; sidx < S; ++sidx) mx = fmaxf(mx, lse[((long)sidx * H + h) * Tq + q]);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const float wgt = exp2f(lse[((long)sidx * H + h) * Tq + q] - mx);
+            const half8 pv = *(const half8*)(parts + ((long)sidx * Tq + q) * HD + c8);
+            wsum += wgt;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)pv[j];
+        }
+        const float inv = 1.f / wsum;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)(acc[j] * inv);
+        *(half8*)(out + (long)q * ldo + c8) = o;
+    }
+}
+
 static int launch_flash40p(const _Float16* Qp, const _Float16* Kp, const _Float16* Vt, _Float16* O, int B, int H, int Tq, int Tk, int Tqp, int Tkp,
                            int ldo, long obs, int kv_div, hipStream_t st) {
     constexpr int NW = 8, NSTG = 6;
@@ -1051,6 +1087,36 @@ int tcl_attention_f16(const void* q, int ldq, long qbs, const void* k, int ldk, 
         return launch_flash<128, 128, 128, 1, 2>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
     }
     return launch_flash<160, 160, 160, 1, 3>(Qp, Kp, Vt, (_Float16*)o, B, H, Tq, Tk, Tqp, Tkp, d, ldo, obs, kv_div, st);
+}
+
+// Split-KV attention for one entry (B = 1): see k_flash_lse.  q [Tq, ldq], k [Tk, ldk], v [Tk, ldv] (head h at column h d), o [Tq, ldo].
+// Tk must be a multiple of 64 nsplit; d = 128.  ws: tcl_attention_splitkv_workspace_bytes(nsplit, H, Tq, Tk, d).
+size_t tcl_attention_splitkv_workspace_bytes(int nsplit, int H, int Tq, int Tk, int d) {
+    const size_t qb = (tcl_attention_q_bytes(nsplit, H, Tq, d) + 1023) / 1024 * 1024, kb = (tcl_attention_kv_bytes(nsplit, H, Tk / (nsplit > 0 ? nsplit : 1), d) + 1023) / 1024 * 1024;
+    return qb + kb + (((size_t)nsplit * Tq * H * d * 2 + 1023) / 1024 * 1024) + (size_t)nsplit * H * Tq * 4 + 1024;
+}
+int tcl_attention_splitkv_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int H, int Tq, int Tk, int d,
+                              float scale, int nsplit, void* ws, hipStream_t st) {
+    TCL_CHECK_ARG(q && k && v && o && ws && H > 0 && Tq > 0 && Tk > 0 && d == 128 && nsplit >= 2 && nsplit <= 16 && Tk % (64 * nsplit) == 0 && ldo >= H * d);
+    const int chunk = Tk / nsplit, Tqp = rup(Tq, 256), Tkp = chunk, DP = 128, KS = DP + 8;
+    char* base = (char*)ws;
+    const size_t qb = (tcl_attention_q_bytes(nsplit, H, Tq, d) + 1023) / 1024 * 1024, kb = (tcl_attention_kv_bytes(nsplit, H, chunk, d) + 1023) / 1024 * 1024;
+    void *ws_q = base, *ws_kv = base + qb;
+    _Float16* parts = (_Float16*)(base + qb + kb);
+    float* lse = (float*)(base + qb + kb + (((size_t)nsplit * Tq * H * d * 2 + 1023) / 1024 * 1024));
+    if (attention_pack(q, ldq, 0, k, ldk, (long)chunk * ldk, v, ldv, (long)chunk * ldv, nsplit, H, Tq, chunk, d, scale, 1, 1, 1, ws_q, ws_kv, st) != TCL_OK) return TCL_ELAUNCH;
+    _Float16* Qp = (_Float16*)ws_q;
+    _Float16* Kp = (_Float16*)ws_kv;
+    _Float16* Vt = Kp + (((size_t)nsplit * H * Tkp * KS + 511) / 512) * 512;
+    constexpr int NSTG = 2, SB = KV_TILE * (128 + 8) * 2 + vt_tile_halves(128) * 2, NPIECE = (SB + 1023) / 1024;
+    const size_t lds = (size_t)NSTG * NPIECE * 1024 + 1024;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_flash_lse<128, 128, 128, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    const int nqb = Tqp / 128;
+    hipLaunchKernelGGL((k_flash_lse<128, 128, 128, 1, 2>), dim3(nsplit * H * nqb), dim3(256), lds, st, Qp, Kp, Vt, parts, H, Tq, chunk, Tqp, Tkp, d, H * d,
+                       (long)Tq * H * d, nqb, lse);
+    hipLaunchKernelGGL(k_attn_merge, dim3(stream_grid((long)Tq * (H * d / 8), 256, 2)), dim3(256), 0, st, parts, lse, (_Float16*)o, nsplit, H, Tq, d, ldo);
+    TCL_LAUNCH_RET();
 }
 
 }  // extern "C"

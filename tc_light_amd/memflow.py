@@ -432,6 +432,12 @@ class MemFlowEngine:
         scale = self.scale * np.log(T) / np.log(self.tal)          # memory_manager_skflow.py:59 (math.log(T, train_avg_length))
         wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P, 128), dtype=torch.uint8, device=d)
         wkv = torch.empty(L.tcl_attention_kv_bytes(1, 1, T, 128), dtype=torch.uint8, device=d)
+        # round 6: one head and one entry leave the flash kernel 114 blocks at 1280x720 -- the keys are cut into chunks that run as batch entries
+        # (tcl_attention_splitkv_f16; TCL_MEMFLOW_SPLITKV = number of chunks, 0 = off)
+        ns = int(os.environ.get("TCL_MEMFLOW_SPLITKV", "3"))
+        if ns >= 2 and (T % (64 * ns) != 0 or -(-P // 128) * ns > 1024):
+            ns = next((c for c in (3, 2, 5, 4, 6) if T % (64 * c) == 0 and -(-P // 128) * c <= 1024), 0)
+        wsp = torch.empty(L.tcl_attention_splitkv_workspace_bytes(ns, 1, P, T, 128), dtype=torch.uint8, device=d) if ns >= 2 else None
         for it in range(self.iters):
             corr_fn.lookup_rows(coords1, corr_rows)
             flow = coords1 - coords0
@@ -444,8 +450,11 @@ class MemFlowEngine:
             val = self._gemm(mf, self.to_v, P)
             v_all = val if mem_v is None else torch.cat([mem_v, val])
             ro = torch.empty(P, 128, dtype=H16, device=d)
-            L.tcl_attention_f16(qk, 256, P * 256, k_all, 128, T * 128, v_all, 128, T * 128, ro, 128, P * 128, 1, 1, P, T, 128, float(scale), 1, 1, wq, wkv,
-                                stream())
+            if ns >= 2:
+                L.tcl_attention_splitkv_f16(qk, 256, k_all, 128, v_all, 128, ro, 128, 1, P, T, 128, float(scale), ns, wsp, stream())
+            else:
+                L.tcl_attention_f16(qk, 256, P * 256, k_all, 128, T * 128, v_all, 128, T * 128, ro, 128, P * 128, 1, 1, P, T, 128, float(scale), 1, 1, wq, wkv,
+                                    stream())
             mfg = torch.empty_like(mf)
             L.tcl_axpy_f16(mf, ro, self.gamma, mfg, mf.numel(), stream())
             net = self._pc(self.gru, self._cat(self._cat(net, inp, P), self._cat(mf, mfg, P), P), 1, h, w)

@@ -232,10 +232,24 @@ def sharded_temporal_pass(d, x_local, cc_full, n_total, items, compute, x_full=N
         return nt_full[lo:hi]
     _, C, h, w = nt_full.shape
     unit = C * h
-    plists = [yt_pieces(items, r, d.world) for r in range(d.world)]
+    # the piece lists and their column-index tensors depend only on the step's item list: built once per distinct list and kept (world x windows
+    # blocking host-to-device copies per denoising step sat inside the timed loop; the yt chunk draws differ per step, so the cache holds a few entries)
+    cache = d.__dict__.setdefault("_yt_cache", {})
+    key = (d.world, tuple((it[0], it[4], tuple(int(c) for c in it[2])) for it in items), str(nt_full.device))
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) > 64:
+            cache.clear()
+        plists = [yt_pieces(items, r, d.world) for r in range(d.world)]
+        idx = {}
+        for pl in plists:
+            for _, _, cols in pl:
+                idx.setdefault(tuple(cols), torch.tensor(cols, dtype=torch.int64, device=nt_full.device))
+        hit = cache[key] = (plists, idx)
+    plists, idx = hit
     pmax = max(sum((f1 - f0) * len(cols) for f0, f1, cols in pl) for pl in plists) * unit
     dev = nt_full.device
-    cidx = lambda cols: torch.tensor(cols, dtype=torch.int64, device=dev)
+    cidx = lambda cols: idx[tuple(cols)]
     send = torch.zeros(pmax, dtype=nt_full.dtype, device=dev)
     off = 0
     for f0, f1, cols in plists[d.rank]:

@@ -102,6 +102,7 @@ class RMBGEngine:
         assert C1 + C2 == c.cin
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         y = torch.empty(B, c.cout, Ho, Wo, dtype=torch.float32, device=self.dev)
+        self.flops = getattr(self, "flops", 0.0) + 2.0 * 9 * c.cin * c.cout * B * Ho * Wo         # algorithmic conv FLOPs executed (bench.py roofline_rmbg)
         self.L.tcl_conv3x3_direct_f32(x1, C1, x2 if x2 is not None else 0, C2, c.w, c.scale, c.shift, resid if resid is not None else 0, y,
                                       B, H, W, c.cout, c.dil, stride, int(relu), stream())
         return y

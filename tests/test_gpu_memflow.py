@@ -184,3 +184,33 @@ def test_corr_lookup_tiled_rows_vs_per_pixel_kernel(dev, monkeypatch):
             assert m.any() and torch.equal(a[m][:, :81], b[m][:, :81])
         else:
             assert 0 < fb < n_tiles // 2
+
+
+def test_attention_splitkv_equals_single_pass(dev):
+    """Round 6: the memory-read attention with the keys cut into chunks that run as batch entries + a merge by the chunks' softmax denominators
+    (tcl_attention_splitkv_f16) against the one-pass kernel and against f32 SDPA: 2 / 3 / 5 chunks, the MemFlowNet shapes (one head, head_dim 128, P queries,
+    T = P or 2 P keys), logits with a heavy tail so the chunks' maxima differ by many bits."""
+    from tc_light_amd.lib import lib, stream
+    L = lib()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for P_, T in ((1000, 1920), (2250, 5760)):
+        qk = torch.randn(P_, 256, device=dev, generator=g).half()
+        k = (torch.randn(T, 128, device=dev, generator=g) * torch.linspace(0.2, 3.0, T, device=dev)[:, None]).half()      # later keys score higher: chunk maxima differ
+        v = torch.randn(T, 128, device=dev, generator=g).half()
+        scale = 128 ** -0.5 * 1.3
+        ref = torch.nn.functional.scaled_dot_product_attention(qk[None, None, :, :128].float(), k[None, None].float(), v[None, None].float(), scale=scale)[0, 0]
+        one = torch.empty(P_, 128, dtype=torch.float16, device=dev)
+        wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P_, 128), dtype=torch.uint8, device=dev)
+        wkv = torch.empty(L.tcl_attention_kv_bytes(1, 1, T, 128), dtype=torch.uint8, device=dev)
+        L.tcl_attention_f16(qk, 256, P_ * 256, k, 128, T * 128, v, 128, T * 128, one, 128, P_ * 128, 1, 1, P_, T, 128, scale, 1, 1, wq, wkv, stream())
+        e_one = ((one.float() - ref).norm() / ref.norm()).item()
+        for ns in (2, 3, 5):
+            if T % (64 * ns):
+                continue
+            ws = torch.empty(L.tcl_attention_splitkv_workspace_bytes(ns, 1, P_, T, 128), dtype=torch.uint8, device=dev)
+            out = torch.full((P_, 128), float("nan"), dtype=torch.float16, device=dev)
+            L.tcl_attention_splitkv_f16(qk, 256, k, 128, v, 128, out, 128, 1, P_, T, 128, scale, ns, ws, stream())
+            torch.cuda.synchronize()
+            e = ((out.float() - ref).norm() / ref.norm()).item()
+            print(f"[split-KV] P {P_} T {T} chunks {ns}: rel-L2 vs f32 SDPA {e:.2e} (one pass {e_one:.2e})")
+            assert torch.isfinite(out.float()).all() and e < max(2 * e_one, 2e-3), (ns, e, e_one)

@@ -114,20 +114,20 @@ def producer_timings(frames, dev, past_flows=None, masks=None):
     eng = MF.MemFlowEngine(MF.seeded_state_dict(MF.memflow_param_shapes(), 31), dev)
     MF.estimate_flows(eng, fr[:4], warm_start=False)                       # shapes met once eagerly, then captured
     t_flow = wall(lambda: MF.estimate_flows(eng, fr, warm_start=False))
-    os.environ["TCL_MEMFLOW_GRAPH"] = "0"
-    try:
-        t_eager = wall(lambda: MF.estimate_flows(eng, fr, warm_start=False))
-        ms, fl, cnt = counted(lambda: MF.estimate_flows(eng, fr, warm_start=False))
-    finally:
-        os.environ.pop("TCL_MEMFLOW_GRAPH", None)
+    ms, fl, cnt = counted(lambda: MF.estimate_flows(eng, fr, warm_start=False))
     pairs = 2 * (n - 1)
+    P8 = (frames.shape[2] // 8) * (frames.shape[3] // 8)
+    fl_attn = 15 * 4.0 * P8 * (2 * P8) * 128                              # the memory read: 15 iterations x (P queries x 2 P keys, head_dim 128)
+    fl_corr = 15 * 4 * 2.0 * P8 * 100 * 256                              # the on-demand correlation windows: 4 levels x 100 points x 256 features per pixel and iteration
     out.update(memflow_ms_per_frame_pair=t_flow / pairs * 1e3, memflow_pairs=pairs)
     out["roofline_memflow"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "ms_per_pair": t_flow / pairs * 1e3,
-                               "ms_per_pair_eager_launches": t_eager / pairs * 1e3, "gemm_class_tflop_per_pair": fl / pairs / 1e12,
-                               "gemm_class_launches_per_pair": cnt / pairs, "gemm_class_event_ms_per_pair": ms / pairs,
-                               "achieved": fl / pairs / (t_flow / pairs) / 1e12, "frac": fl / t_flow / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS,
-                               "note": "15 GMA-SK2 iterations on a 90x160 grid: ~1 000 launches of 5-40 us per pair (M = 14 400 rows) -- launch-bound, not matrix-bound; "
-                                       "`achieved` = GEMM / conv FLOPs per pair / WALL time per pair (graph replay)"}
+                               "gemm_class_tflop_per_pair": fl / pairs / 1e12, "gemm_class_launches_per_pair": cnt / pairs, "gemm_class_event_ms_per_pair": ms / pairs,
+                               "attention_tflop_per_pair": fl_attn / 1e12, "correlation_tflop_per_pair": fl_corr / 1e12,
+                               "achieved": (fl / pairs + fl_attn + fl_corr) / (t_flow / pairs) / 1e12,
+                               "frac": (fl / pairs + fl_attn + fl_corr) / (t_flow / pairs) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                               "note": "15 GMA-SK2 iterations on a 90x160 grid (M = 14 400 rows): ~1 000 kernels of 5-260 us per pair.  Not launch-bound (the kernel table sums to the wall "
+                                       "clock, profiles/r6_memflow_kernel_stats.txt) and not matrix-bound: small-M GEMMs, a one-head attention, depthwise convolutions and gathers. "
+                                       "`achieved` = (GEMM / conv + attention + correlation FLOPs) per pair / wall time per pair"}
     del eng
     rm = RM.RMBGEngine(RM.random_state_dict(1), dev)
     rm.estimate_alpha(fr[:2])

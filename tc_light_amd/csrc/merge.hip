@@ -215,10 +215,14 @@ __global__ __launch_bounds__(256, 3) void k_tome_match(const _Float16* __restric
 // (no index loads in the loop, so the counted vmcnt only ever sees the LDS-DMA).  XCD x sweeps dst split x % nsplit: its L2 holds one range.
 // LDS image of a stage: row R at R * 128, its 16-B chunk g stored at position g ^ ((R >> 1) & 7): the 16-lane groups of a ds_read_b128
 // (MI355X_MICROARCH.md, LDS table) then touch 16 distinct slots of the 256-B bank window.
-template <int NW, int C = 320>        // waves per block: 4 (128-src strip, two blocks per CU) or 8 (256-src strip, one block per CU: half the dst DMA per MFMA); C = 640 (round 4): the level-1 matches, 160 VGPRs of strip
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
+// Round 6 -- NS = 2, TR = 64: the LDS bound of this kernel.  Every wave of a block reads the SAME dst rows from LDS as the A operand of its MFMAs: 1 KiB per 32x32x16 MFMA, and a CU
+// that issues one MFMA per 8 clocks (its four matrix pipes' rate) needs exactly the LDS's 128 B/clk -- the 54 % the matrix pipe showed (profiles/r2_tome_match320_sq_counters.txt) is that
+// bound at ~2/3 LDS efficiency, and the flash kernel the chain runs beside lives on the same LDS.  With TWO src sub-tiles per wave (2 x 80 VGPRs of strip) every A fragment feeds two
+// MFMAs: half the LDS reads and half the dst DMA per MFMA; the dst tile shrinks to 64 rows so the accumulators stay at 64 VGPRs.  Same MFMA, same K order, same tile order: same keys.
+template <int NW, int C = 320, int NS = 1, int TR = 128>        // waves per block: 4 (128-src strip, two blocks per CU) or 8 (256-src strip, one block per CU: half the dst DMA per MFMA); C = 640 (round 4): the level-1 matches, 160 VGPRs of strip
+__global__ __launch_bounds__(64 * NW, (NW == 4 && NS == 1) ? 2 : 1) void k_tome_match320(const _Float16* __restrict__ metric, long bstride, int Bt, int a_split, int a_gap, int na,
                                                           int b0, int nb, int tiles_dst, int nsplit, unsigned long long* __restrict__ keys) {
-    constexpr int NST = C / 64, STAGE = 128 * 128, SW = 32 * NW, NP = 16 / NW;       // src strip width, DMA pieces per wave and stage
+    constexpr int NST = C / 64, STAGE = TR * 128, SW = 32 * NW * NS, NP = (TR / 8) / NW, NA = TR / 32;       // src strip width, DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* const lds0 = (__attribute__((address_space(3))) char*)smem;
     const int bid = blockIdx.x, x = bid & 7, per = 8 / nsplit;
@@ -234,26 +238,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
     // lowest index unchanged.
     const int rr = lane >> 3, ch = lane & 7;
     const int voff0 = rr * (C * 2) + ((ch ^ (rr >> 1)) << 4), voff1 = rr * (C * 2) + ((ch ^ (4 + (rr >> 1))) << 4);
-    const int si = strip * SW + wid * 32 + col;                                    // this lane's src column
-    const long srow = si < na ? (long)(si < a_split ? si : si + a_gap) * C : -1;
+    int si[NS]; long srow[NS];                                                     // this lane's src column(s)
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) { si[s_] = strip * SW + (wid * NS + s_) * 32 + col; srow[s_] = si[s_] < na ? (long)(si[s_] < a_split ? si[s_] : si[s_] + a_gap) * C : -1; }
     const int ntl = t1 - t0, nstep = ntl * NST;
-    _Float16 pm = (_Float16)(-65504.f);                                             // running maximum of the lane's f16-rounded scores
-    int bi = 0x7fffffff;                                                            // concatenated dst index where it was first attained
+    _Float16 pm[NS]; int bi[NS];                                                    // running maximum of the lane's f16-rounded scores; concatenated dst index where it was first attained
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) { pm[s_] = (_Float16)(-65504.f); bi[s_] = 0x7fffffff; }
     for (int bb = 0; bb < Bt; ++bb) {
         const _Float16* base = metric + (long)bb * bstride;
-        half8 bfr[C / 16];                                                          // B operand: src column, k = 16 ks + 8 hl .. + 7
+        half8 bfr[NS][C / 16];                                                      // B operand: src column, k = 16 ks + 8 hl .. + 7
 #pragma unroll
-        for (int ks = 0; ks < C / 16; ++ks) {
-            if (srow >= 0) bfr[ks] = *(const half8*)(base + srow + ks * 16 + 8 * hl);
-            else
+        for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bfr[ks][j] = (_Float16)0.f;
-        }
+            for (int ks = 0; ks < C / 16; ++ks) {
+                if (srow[s_] >= 0) bfr[s_][ks] = *(const half8*)(base + srow[s_] + ks * 16 + 8 * hl);
+                else
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bfr[s_][ks][j] = (_Float16)0.f;
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the fragment loads are the only non-DMA VMEM reads: drain before counting
         int i_t = 0, i_k = 0;                                                       // (tile, stage) of the step being ISSUED
 #define T320_ISSUE(BUF)                                                                                                       \
         {                                                                                                                     \
-            const int dj0_ = min((t0 + i_t) * 128, nb - 128);                                                                 \
+            const int dj0_ = min((t0 + i_t) * TR, nb - TR);                                                                   \
             const char* sb_ = (const char*)base + ((long)(b0 + dj0_ + wid * (8 * NP)) * C + i_k * 64) * 2;                    \
             _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                 \
                 const char* src_ = sb_ + i * (8 * C * 2) + ((i & 1) ? voff1 : voff0);                                         \
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
         if (nstep > 1) T320_ISSUE(1);
         int step = 0;
         for (int tl = 0; tl < ntl; ++tl) {
-            float16v acc[4];
+            float16v acc[NS][NA];
 #pragma unroll
             for (int kt = 0; kt < NST; ++kt, ++step) {
                 // 4-slot ring, two K stages per barrier: steps s, s+1 (s even) are consumed while s+2, s+3 stream into the slots of s-2, s-1
@@ -281,56 +289,63 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_tome_match320(cons
                 // A fragments one k-slice ahead of the MFMAs that use them: the LDS latency of slice ks+1 hides under the 4 MFMAs of slice ks
                 // (with the reads issued right before their MFMAs the waves sat parked 45 % of their cycles, matrix pipe 44 % busy)
                 constexpr bool PF = C <= 320;                                       // C = 640: the strip takes 160 VGPRs -- no second fragment set (the two waves of a SIMD cover for each other)
-                half8 fa[PF ? 2 : 1][4];
+                half8 fa[PF ? 2 : 1][NA];
                 if (PF) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[0][a] = *(const half8*)(db + R * 128 + (((0 + hl) ^ ((R >> 1) & 7)) << 4)); }
+                    for (int a = 0; a < NA; ++a) { const int R = a * 32 + col; fa[0][a] = *(const half8*)(db + R * 128 + (((0 + hl) ^ ((R >> 1) & 7)) << 4)); }
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     if (PF ? ks < 3 : true) {
                         const int kn = PF ? ks + 1 : ks;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) { const int R = a * 32 + col; fa[PF ? (kn & 1) : 0][a] = *(const half8*)(db + R * 128 + (((2 * kn + hl) ^ ((R >> 1) & 7)) << 4)); }
+                        for (int a = 0; a < NA; ++a) { const int R = a * 32 + col; fa[PF ? (kn & 1) : 0][a] = *(const half8*)(db + R * 128 + (((2 * kn + hl) ^ ((R >> 1) & 7)) << 4)); }
                     }
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        if (kt == 0 && ks == 0) {
-                            float16v z;
+                    for (int a = 0; a < NA; ++a)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][a], bfr[0], z, 0, 0, 0);
-                        } else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PF ? (ks & 1) : 0][a], bfr[kt * 4 + ks], acc[a], 0, 0, 0);
-                    }
+                        for (int s_ = 0; s_ < NS; ++s_) {
+                            if (kt == 0 && ks == 0) {
+                                float16v z;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                                acc[s_][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][a], bfr[s_][0], z, 0, 0, 0);
+                            } else acc[s_][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PF ? (ks & 1) : 0][a], bfr[s_][kt * 4 + ks], acc[s_][a], 0, 0, 0);
+                        }
                 }
             }
             // ---- score tile (128 dst x 32 src per wave) -> running maximum.  f32 -> f16 rounding is monotonic, so the maximum of the 16
             // rounded scores a lane holds of a 32-row tile is the rounded f32 maximum: 8 v_max3 + one conversion instead of 8 cvt_pk + 8
             // pk_max; the conversions of all 16 and the lowest-index scan run only when the running maximum grew (~ln(tiles) times).
-            const int dj0 = min((t0 + tl) * 128, nb - 128), cat0 = bb * nb + dj0 + 4 * hl;
+            const int dj0 = min((t0 + tl) * TR, nb - TR), cat0 = bb * nb + dj0 + 4 * hl;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                float t = fmaxf(fmaxf(acc[a][0], acc[a][1]), acc[a][2]);
+            for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
-                for (int r = 3; r < 15; r += 2) t = fmaxf(fmaxf(t, acc[a][r]), acc[a][r + 1]);
-                t = fmaxf(t, acc[a][15]);
+            for (int a = 0; a < NA; ++a) {
+                float t = fmaxf(fmaxf(acc[s_][a][0], acc[s_][a][1]), acc[s_][a][2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) t = fmaxf(fmaxf(t, acc[s_][a][r]), acc[s_][a][r + 1]);
+                t = fmaxf(t, acc[s_][a][15]);
                 const _Float16 th = (_Float16)t;
-                if (__any(th > pm)) {                                               // some lane's running maximum grew inside this 32-row tile
+                if (__any(th > pm[s_])) {                                           // some lane's running maximum grew inside this 32-row tile
                     asm volatile("; record");                                       // (a real branch: the scan below is the expensive part)
                     int rlo = 0;                                                    // lowest element attaining the tile maximum (descending scan)
 #pragma unroll
-                    for (int r = 15; r >= 0; --r) rlo = (_Float16)acc[a][r] == th ? r : rlo;
-                    if (th > pm) { pm = th; bi = cat0 + a * 32 + (rlo & 3) + 8 * (rlo >> 2); }
+                    for (int r = 15; r >= 0; --r) rlo = (_Float16)acc[s_][a][r] == th ? r : rlo;
+                    if (th > pm[s_]) { pm[s_] = th; bi[s_] = cat0 + a * 32 + (rlo & 3) + 8 * (rlo >> 2); }
                 }
             }
         }
 #undef T320_ISSUE
         __builtin_amdgcn_s_barrier();                                               // everyone is done reading the ring before the next batch refills it
     }
-    unsigned long long best = ((unsigned long long)sortable16(pm) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bi);
-    const unsigned long long other = __shfl_xor(best, 32, 64);
-    best = other > best ? other : best;
-    if (hl == 0 && si < na) atomicMax(keys + si, best);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        unsigned long long best = ((unsigned long long)sortable16(pm[s_]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bi[s_]);
+        const unsigned long long other = __shfl_xor(best, 32, 64);
+        best = other > best ? other : best;
+        if (hl == 0 && si[s_] < na) atomicMax(keys + si[s_], best);
+    }
 }
 
 // Top-r selection and map construction without a sort, in TWO launches per match (round 4; rounds 2-3: five -- two histogram passes, two
@@ -551,7 +566,12 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
         (void)hipFuncSetAttribute((const void*)(k_tome_match320<4, 640>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds320);
         set = true;
     }
-    static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 1;      // tuning / A-B hook: 0 = always the tile-epilogue kernel
+    // tuning / A-B hook: 0 = always the tile-epilogue kernel, 4 / 8 = one src sub-tile per wave (rounds 2-5; 4- / 8-wave blocks), 2 (default since round 6) = two src
+    // sub-tiles per wave on 64-row dst tiles.  Round 6, same box (profiles/r6_ab_tome_x2_alone.txt, r6_ab_tome_x2_inpass.txt): ALONE the 2-sub-tile form is 4-27 % SLOWER
+    // (276 unified registers: one wave per SIMD where the old form ran two; 43 200 x 14 400: 946 -> 1 070 us) -- and IN THE PASS, where its neighbour on the SIMD is a flash
+    // wave either way and the LDS is shared with that kernel, the 60-frame denoise phase is 0.8 % faster in both interleaved pairs (33.26 / 33.31 -> 33.02 / 33.04 s).
+    // The pass is what counts.  Same keys bit for bit (test_tome_match_strip_kernel_equals_tile_kernel passes under TCL_TOME320=2 and =4).
+    static const int use320 = getenv("TCL_TOME320") ? atoi(getenv("TCL_TOME320")) : 2;
     // C = 640 (level 1) on the strip kernel: built in round 4 (VERDICT r3 #3a), bit-identical, 5-24 % faster per call alone (tools/micro/bench_tome.py:
     // 7 920 x 7 920: 269 -> 205 us) -- and 0.3 % SLOWER in the pass (same-box A/B, profiles/r4_ab_tome640.txt): its strip takes 160 of a wave's 256
     // registers, so a block only starts on a SIMD with 256 free registers, i.e. not beside two flash waves.  Off by default; TCL_TOME640=1 selects it.
@@ -563,11 +583,17 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
         // block (352 VGPRs per SIMD lane, 64 KiB LDS) only starts on a CU that holds NO flash block, where a 4-wave block shares one with a flash
         // block -- in the profiled pass the 8-wave launches took 2.2 ms on average against 0.9 alone.  use320 = 8 selects it (tools/micro/bench_tome.py).
         const int nw = (use320 == 8 && C == 320) ? 8 : 4;
-        const int tsw = cdiv(na, 32 * nw), slots = nw == 8 ? 256 : 512;
+        const bool x2 = use320 == 2 && C == 320;             // round 6: two src sub-tiles per wave, 64-row dst tiles (half the LDS reads and dst DMA per MFMA)
+        const int tsw = cdiv(na, x2 ? 256 : 32 * nw), slots = (nw == 8 || x2) ? 256 : 512, tdx = x2 ? cdiv(nb, 64) : td;
         int nsplit = 1;
         while (nsplit < 8 && (long)tsw * nsplit < slots * 3 / 2) nsplit *= 2;
-        while (nsplit > 1 && cdiv(td, nsplit) < 2) nsplit /= 2;
+        while (nsplit > 1 && cdiv(tdx, nsplit) < 2) nsplit /= 2;
         const int per = 8 / nsplit, groups = cdiv(tsw, per);
+        if (x2) {
+            static bool set2 = false;
+            if (!set2) { (void)hipFuncSetAttribute((const void*)(k_tome_match320<4, 320, 2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128); set2 = true; }
+            hipLaunchKernelGGL((k_tome_match320<4, 320, 2, 64>), dim3(groups * 8), dim3(256), (size_t)4 * 64 * 128, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, tdx, nsplit, keys);
+        } else
         if (C == 640) hipLaunchKernelGGL((k_tome_match320<4, 640>), dim3(groups * 8), dim3(256), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
         else if (nw == 8) hipLaunchKernelGGL(k_tome_match320<8>, dim3(groups * 8), dim3(512), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);
         else hipLaunchKernelGGL(k_tome_match320<4>, dim3(groups * 8), dim3(256), lds320, st, (const _Float16*)metric, bstride, Bt, a_split, a_gap, na, b0, nb, td, nsplit, keys);

@@ -96,11 +96,12 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ f
 // needs the rows of ONE bounding box of ~(8 / 2^l + 10)^2 points.  A block therefore stages that box, 32 features at a time, in LDS (f16: level 0 is
 // the encoder's f16 output as it stands, the pooled levels are rounded once), and every thread takes a quarter of one pixel's 100 window points:
 // 25 dot products per thread on v_dot2_f32_f16 with f32 accumulation in a fixed order (deterministic), the bilinear mix of corr.py:95-112 last, same formula and
-// order as k_corr_lookup.  166 KB instead of 6.5 MB of L2 reads per tile and level.  A tile whose box exceeds CRMAX points (a flow that tears the tile
-// apart) raises its flag and is left to k_corr_lookup, launched behind with the flags as a filter.
+// order as k_corr_lookup.  166 KB instead of 6.5 MB of L2 reads per tile and level.  A box of more than CT_RMAX points is staged in bands of whole rows (up to
+// CT_MAXB); a tile whose box exceeds that (a flow that tears the tile apart) raises its flag and is left to k_corr_lookup, launched behind with the flags as a filter.
 #define CT_K 32            // features per LDS slice
 #define CT_STR 40          // LDS row stride in halves: 80 B = 5 x 16 B, odd -> 16-byte reads of 64 different rows are conflict-free
-#define CT_RMAX 512        // box points a block stages (22 x 23); one more all-zero row stands in for points outside the image / the box
+#define CT_RMAX 512        // box points a block stages per band (22 x 23); one more all-zero row stands in for points outside the image / the box / the band
+#define CT_MAXB 8          // bands per tile before the per-pixel kernel takes over
 struct CorrLevelsH { const _Float16* f2[4]; int H[4], W[4]; };
 typedef _Float16 ch8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ch2 __attribute__((ext_vector_type(2)));
@@ -141,48 +142,59 @@ __global__ __launch_bounds__(256, 2) void k_corr_lookup_tile(const _Float16* __r
     __syncthreads();
     const int bx0 = s_box[0], by0 = s_box[1], bw = s_box[2], bh = s_box[3];
     const bool empty = bw <= 0 || bh <= 0;
-    const long nreg_l = empty ? 0 : (long)bw * bh;
-    if (nreg_l > CT_RMAX) { if (tid == 0) tile_flags[l * gridDim.x + tile] = 1; return; }      // block-uniform: left to k_corr_lookup
+    // a box of more than CT_RMAX points is taken in BANDS of whole box rows (each band one staging pass per feature slice; a window point contributes in the band
+    // that holds its row, the accumulators live across bands): up to CT_MAXB bands -- 4 096 points, a 64 x 64 box -- still cost less than the per-pixel kernel's
+    // 100 L2 rows per pixel; beyond that (or a box wider than CT_RMAX) the tile raises its flag and is left to k_corr_lookup.  Block-uniform decisions.
+    const int rows_pb = empty ? 1 : max(CT_RMAX / max(bw, 1), 0), nbands = empty ? 0 : (rows_pb > 0 ? (bh + rows_pb - 1) / rows_pb : CT_MAXB + 1);
+    if (nbands > CT_MAXB) { if (tid == 0) tile_flags[l * gridDim.x + tile] = 1; return; }
     if (tid == 0) tile_flags[l * gridDim.x + tile] = 0;
-    const int nreg = (int)nreg_l;
-    // this thread's 25 window points -> LDS row offsets (halves); outside the image (= outside the clipped box): the zero row
-    int off[PT];
+    // this thread's 25 window points -> (box row, box column), -1 outside the image (= outside the clipped box)
+    int ryx[PT];
     {
         const int x0 = s_x0[pixl], y0 = s_y0[pixl];
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int p = part * PT + j, ry = y0 + p / N1 - by0, rx = x0 + p % N1 - bx0;
-            off[j] = (live && !empty && ry >= 0 && ry < bh && rx >= 0 && rx < bw) ? (ry * bw + rx) * CT_STR : CT_RMAX * CT_STR;
+            ryx[j] = (live && !empty && ry >= 0 && ry < bh && rx >= 0 && rx < bw) ? ((ry << 12) | rx) : -1;      // bw <= CT_RMAX = 512 < 4096
         }
     }
     float acc[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) acc[j] = 0.f;
     const _Float16* __restrict__ q = f1 + (long)pix * D;
-    for (int ks = 0; ks < D; ks += CT_K) {
-        __syncthreads();                                  // the previous slice has been read by everybody
-        for (int i = tid >> 2; i < nreg; i += 64) {      // 4 threads per row: 4 x 16 B = the row's 32 features of this slice
-            const int iy = by0 + i / bw, ix = bx0 + i % bw;
-            *(ch8*)(reg + i * CT_STR + (tid & 3) * 8) = *(const ch8*)(g + ((long)iy * Wl + ix) * D + ks + (tid & 3) * 8);
-        }
-        ch8 qv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) qv[c] = *(const ch8*)(q + ks + c * 8);
-        __syncthreads();
+    for (int band = 0; band < nbands; ++band) {
+        const int y_lo = band * rows_pb, y_hi = min(y_lo + rows_pb, bh), nreg = (y_hi - y_lo) * bw;
+        int off[PT];                                       // LDS row offsets (halves) of the window points inside this band; the zero row otherwise
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const _Float16* row = reg + off[j];
-            float a = acc[j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const ch8 v = *(const ch8*)(row + c * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const ch2 a2 = {qv[c][2 * e], qv[c][2 * e + 1]}, b2 = {v[2 * e], v[2 * e + 1]};
-                    a = __builtin_amdgcn_fdot2(a2, b2, a, false);
-                }
+            const int ry = ryx[j] >> 12, rx = ryx[j] & 4095;
+            off[j] = (ryx[j] >= 0 && ry >= y_lo && ry < y_hi) ? ((ry - y_lo) * bw + rx) * CT_STR : CT_RMAX * CT_STR;
+        }
+        for (int ks = 0; ks < D; ks += CT_K) {
+            __syncthreads();                                  // the previous slice has been read by everybody
+            for (int i = tid >> 2; i < nreg; i += 64) {      // 4 threads per row: 4 x 16 B = the row's 32 features of this slice
+                const int iy = by0 + y_lo + i / bw, ix = bx0 + i % bw;
+                *(ch8*)(reg + i * CT_STR + (tid & 3) * 8) = *(const ch8*)(g + ((long)iy * Wl + ix) * D + ks + (tid & 3) * 8);
             }
-            acc[j] = a;
+            ch8 qv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[c] = *(const ch8*)(q + ks + c * 8);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const _Float16* row = reg + off[j];
+                float a = acc[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const ch8 v = *(const ch8*)(row + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const ch2 a2 = {qv[c][2 * e], qv[c][2 * e + 1]}, b2 = {v[2 * e], v[2 * e + 1]};
+                        a = __builtin_amdgcn_fdot2(a2, b2, a, false);
+                    }
+                }
+                acc[j] = a;
+            }
         }
     }
 #pragma unroll

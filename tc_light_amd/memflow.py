@@ -430,14 +430,15 @@ class MemFlowEngine:
         k_all = key if mem_k is None else torch.cat([mem_k, key])
         T = k_all.shape[0]
         scale = self.scale * np.log(T) / np.log(self.tal)          # memory_manager_skflow.py:59 (math.log(T, train_avg_length))
-        wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P, 128), dtype=torch.uint8, device=d)
-        wkv = torch.empty(L.tcl_attention_kv_bytes(1, 1, T, 128), dtype=torch.uint8, device=d)
         # round 6: one head and one entry leave the flash kernel 114 blocks at 1280x720 -- the keys are cut into chunks that run as batch entries
         # (tcl_attention_splitkv_f16; TCL_MEMFLOW_SPLITKV = number of chunks, 0 = off)
         ns = int(os.environ.get("TCL_MEMFLOW_SPLITKV", "3"))
         if ns >= 2 and (T % (64 * ns) != 0 or -(-P // 128) * ns > 1024):
             ns = next((c for c in (3, 2, 5, 4, 6) if T % (64 * c) == 0 and -(-P // 128) * c <= 1024), 0)
         wsp = torch.empty(L.tcl_attention_splitkv_workspace_bytes(ns, 1, P, T, 128), dtype=torch.uint8, device=d) if ns >= 2 else None
+        if ns < 2:
+            wq = torch.empty(L.tcl_attention_q_bytes(1, 1, P, 128), dtype=torch.uint8, device=d)
+            wkv = torch.empty(L.tcl_attention_kv_bytes(1, 1, T, 128), dtype=torch.uint8, device=d)
         for it in range(self.iters):
             corr_fn.lookup_rows(coords1, corr_rows)
             flow = coords1 - coords0

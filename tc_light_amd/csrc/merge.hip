@@ -417,6 +417,36 @@ __global__ __launch_bounds__(THR_BS) void k_thr_select(const unsigned long long*
     for (int q = 0; q < 64; ++q) zb[q] = z4;                                  // bins back to zero for the next match
     if (tid == 0) ctrl[0] = 0;
 }
+// Round 6: the same selection in ONE block without global bins -- a two-pass radix select over the high / low byte of the 16-bit sortable score with 256-bin LDS
+// histograms (the keys are <= 64 k x 8 B in L2: read twice).  k_thr_select needs 2-64 blocks resident at once, and beside the flash kernel and the score kernels every
+// block of a side-stream launch waits for a CU slot: 60 us per launch in the pass against ~10 alone (profiles/r6_bench_kernel_stats.txt).  One block waits once.
+// Same threshold and tie count: thr = the largest score with #(score > thr) < r <= #(score >= thr), take = r - #(score > thr).
+__global__ __launch_bounds__(1024) void k_thr_select1(const unsigned long long* __restrict__ keys, int na, int r, int* __restrict__ ctrl) {
+    __shared__ int h[256], s_b, s_above;
+    const int tid = threadIdx.x;
+    if (r <= 0) { if (tid == 0) { ctrl[2] = 0x10000; ctrl[3] = 0; } return; }          // nothing merged (block-uniform)
+    int bucket = 0, above = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (tid < 256) h[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < na; i += 1024) {
+            const int s16 = (int)((keys[i] >> 32) & 0xFFFFu);
+            if (pass == 0) atomicAdd(&h[s16 >> 8], 1);
+            else if ((s16 >> 8) == bucket) atomicAdd(&h[s16 & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            int ab = above;                                                            // keys strictly above this bin (within the running prefix)
+            for (int b = 255; b > tid; --b) ab += h[b];
+            if (ab < r && r <= ab + h[tid]) { s_b = tid; s_above = ab; }               // exactly one bin satisfies this (r <= the keys counted so far)
+        }
+        __syncthreads();
+        if (pass == 0) { bucket = s_b; above = s_above; }
+        else if (tid == 0) { ctrl[2] = (bucket << 8) | s_b; ctrl[3] = r - s_above; }
+        __syncthreads();
+    }
+}
 #define TOME_MAPS_BS 256
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -606,8 +636,12 @@ static int tome_match_impl(const void* metric, long bstride, int Bt, int C, cons
     hipLaunchKernelGGL(k_tome_match, dim3(cdiv(td, 8) * 8 * nrange, Bt), dim3(256), lds, st, (const _Float16*)metric, bstride, C, a_pos, na, b_pos, nb, ts, td,
                        spb, keys);
     }
-    const int hg = na >= 16384 ? 64 : (na >= 2048 ? 16 : 2);
-    hipLaunchKernelGGL(k_thr_select, dim3(hg), dim3(THR_BS), 0, st, keys, na, r, hist16, ctrl);
+    static const int thr1 = getenv("TCL_THR1") ? atoi(getenv("TCL_THR1")) : 1;      // 0 = the multi-block histogram kernel of round 4
+    if (thr1) hipLaunchKernelGGL(k_thr_select1, dim3(1), dim3(1024), 0, st, keys, na, r, ctrl);
+    else {
+        const int hg = na >= 16384 ? 64 : (na >= 2048 ? 16 : 2);
+        hipLaunchKernelGGL(k_thr_select, dim3(hg), dim3(THR_BS), 0, st, keys, na, r, hist16, ctrl);
+    }
     const int nsb = cdiv(na, TOME_MAPS_BS);
     hipLaunchKernelGGL(k_tome_maps2, dim3(nsb + cdiv(nb, TOME_MAPS_BS)), dim3(TOME_MAPS_BS), 0, st, keys, ctrl, na, nb, r, nsb, a_pos, b_pos, mrg, unm);
     TCL_LAUNCH_RET();
